@@ -1,0 +1,222 @@
+"""ctypes front end of the CPU oracle (oracle/dsp_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by
+the cpu_baseline leg of bench.py -- never by the product package dsp_amd/.
+Function names and return tuples mirror the reference's Python functions so
+the parity tests read like calls into the reference:
+
+    rrc_filter                read_file.py:5-36
+    convolve_same / np_std    worker.py:173-178
+    gardner_timing_recovery   gardner2.py:6-100
+    gardner_ted               hw1/gardner.py:22-74, read_file.py:53-104
+    fll_func                  fll_func.py:3-29
+    lagrange_resample         hw1/test_lagrange_resampling.py:34-72
+    read_iq_int16             hw1/gardner.py:77-91
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile liboracle.so with gcc (seconds)."""
+    src = os.path.join(_HERE, "dsp_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liboracle.so"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        i64, dbl, vp, ci = C.c_int64, C.c_double, C.c_void_p, C.c_int
+        L.orc_sum.restype = dbl
+        L.orc_sum.argtypes = [vp, i64]
+        L.orc_rrc_taps.restype = i64
+        L.orc_rrc_taps.argtypes = [ci, ci, dbl, vp, i64]
+        L.orc_conv_same.restype = ci
+        L.orc_conv_same.argtypes = [vp, i64, vp, i64, vp]
+        L.orc_std_complex.restype = dbl
+        L.orc_std_complex.argtypes = [vp, i64]
+        L.orc_scale_complex.restype = None
+        L.orc_scale_complex.argtypes = [vp, i64, dbl]
+        L.orc_gardner2.restype = i64
+        L.orc_gardner2.argtypes = [vp, i64, ci, dbl, dbl, vp, vp, vp, i64]
+        L.orc_gardner_ted.restype = i64
+        L.orc_gardner_ted.argtypes = [vp, i64, ci, dbl, vp, vp, vp, i64]
+        L.orc_fll.restype = dbl
+        L.orc_fll.argtypes = [vp, i64, dbl, dbl, vp, vp, vp]
+        L.orc_fll_state.restype = dbl
+        L.orc_fll_state.argtypes = [vp, i64, dbl, dbl, i64, vp, vp, vp, vp, vp]
+        L.orc_quadrants.restype = None
+        L.orc_quadrants.argtypes = [vp, i64, vp]
+        L.orc_lagrange_resample.restype = ci
+        L.orc_lagrange_resample.argtypes = [vp, i64, vp, i64, ci, vp]
+        L.orc_read_iq_int16.restype = i64
+        L.orc_read_iq_int16.argtypes = [vp, i64, ci, vp]
+        L.orc_read_iq_f32.restype = i64
+        L.orc_read_iq_f32.argtypes = [vp, i64, vp]
+        L.orc_sync_chain_c64.restype = i64
+        L.orc_sync_chain_c64.argtypes = [vp, i64, dbl, ci, dbl, dbl, dbl, dbl,
+                                         vp, vp, vp, vp, vp, vp, vp]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _c128(x):
+    return np.ascontiguousarray(x, dtype=np.complex128)
+
+
+# ---------------------------------------------------------------------------
+def rrc_filter(sps, span, alpha):
+    n = (span * sps) // 2 + 1 - ((-span * sps) // 2)
+    h = np.zeros(max(n, 0), dtype=np.float64)
+    got = lib().orc_rrc_taps(int(sps), int(span), float(alpha), _p(h), h.size)
+    assert got == h.size, (got, h.size)
+    return h
+
+
+def convolve_same(x, h):
+    x = _c128(x)
+    h = np.ascontiguousarray(h, dtype=np.float64)
+    y = np.empty_like(x)
+    rc = lib().orc_conv_same(_p(x), x.size, _p(h), h.size, _p(y))
+    if rc != 0:
+        raise ValueError("orc_conv_same needs len(x) >= len(h) > 0")
+    return y
+
+
+def np_std(y):
+    y = _c128(y)
+    return lib().orc_std_complex(_p(y), y.size)
+
+
+def filter_samples(x, h):
+    """worker.py:173-178: convolve 'same' then / np.std."""
+    y = convolve_same(x, h)
+    s = np_std(y)
+    lib().orc_scale_complex(_p(y), y.size, s)
+    return y
+
+
+def gardner_timing_recovery(signal, sps, alpha=0.007, mu_initial=0.0):
+    x = _c128(signal)
+    if x.size == 0:
+        raise IndexError("index 0 is out of bounds for axis 0 with size 0")
+    cap = x.size // max(int(sps), 1) + 8
+    rec = np.empty(cap, np.complex128)
+    err = np.empty(cap, np.float64)
+    mu = np.empty(cap, np.float64)
+    n = lib().orc_gardner2(_p(x), x.size, int(sps), float(alpha), float(mu_initial),
+                           _p(rec), _p(err), _p(mu), cap)
+    if n < 0:
+        raise RuntimeError(f"orc_gardner2 failed ({n})")
+    return rec[:n].copy(), err[:n - 1].copy(), mu[:n - 1].copy()
+
+
+def gardner_ted(x, sps, delta_mu=0.002):
+    x = _c128(x)
+    cap = max(x.size // max(int(sps), 1) + 8, 8)
+    y = np.empty(cap, np.complex128)
+    err = np.empty(cap, np.float64)
+    mu = np.empty(cap, np.float64)
+    n = lib().orc_gardner_ted(_p(x), x.size, int(sps), float(delta_mu), _p(y), _p(err), _p(mu), cap)
+    if n < 0:
+        raise RuntimeError(f"orc_gardner_ted failed ({n})")
+    return y[:n].copy(), err[:n].copy(), mu[:n].copy()
+
+
+def fll_func(signal, Bn=0.001, y=1):
+    x = _c128(signal)
+    out = np.empty(x.size, np.complex128)
+    freq = np.empty(x.size, np.float64)
+    ef = np.empty(x.size, np.float64)
+    cf = lib().orc_fll(_p(x), x.size, float(Bn), float(y), _p(out), _p(freq), _p(ef))
+    return out, cf, freq, ef
+
+
+def fll_state(signal, Bn, y, i0=0, state=None):
+    """fll_func continued from (curr_freq, integrator) at absolute index i0."""
+    x = _c128(signal)
+    out = np.empty(x.size, np.complex128)
+    freq = np.empty(x.size, np.float64)
+    ef = np.empty(x.size, np.float64)
+    st_in = np.asarray(state, np.float64) if state is not None else None
+    st_out = np.zeros(2, np.float64)
+    lib().orc_fll_state(_p(x), x.size, float(Bn), float(y), int(i0), _p(st_in), _p(st_out),
+                        _p(out), _p(freq), _p(ef))
+    return out, freq, ef, st_out
+
+
+def quadrants(z):
+    z = _c128(z)
+    q = np.empty(z.size, np.uint8)
+    lib().orc_quadrants(_p(z), z.size, _p(q))
+    return q
+
+
+def lagrange_resample(signal, positions, half_len=4):
+    sig = np.asarray(signal)
+    x = _c128(sig)
+    pos = np.ascontiguousarray(positions, dtype=np.float64)
+    out = np.empty(pos.size, np.complex128)
+    rc = lib().orc_lagrange_resample(_p(x), x.size, _p(pos), pos.size, int(half_len), _p(out))
+    if rc != 0:
+        raise ValueError("orc_lagrange_resample: bad arguments")
+    return out.astype(sig.dtype) if np.iscomplexobj(sig) else out.real.astype(sig.dtype)
+
+
+def read_iq_int16_words(raw, normalize=True):
+    raw = np.ascontiguousarray(raw, dtype=np.int16)
+    out = np.empty(raw.size // 2, np.complex64)
+    n = lib().orc_read_iq_int16(_p(raw), raw.size, int(bool(normalize)), _p(out))
+    if n < 0:
+        raise ValueError("need at least one I/Q pair")
+    return out[:n]
+
+
+def read_iq_int16(path, normalize=True):
+    return read_iq_int16_words(np.fromfile(path, dtype=np.int16), normalize)
+
+
+def read_iq_f32_words(raw):
+    raw = np.ascontiguousarray(raw, dtype=np.float32)
+    out = np.empty(raw.size // 2, np.complex64)
+    lib().orc_read_iq_f32(_p(raw), raw.size, _p(out))
+    return out
+
+
+def sync_chain_c64(x, sps=4, alpha=0.007, mu0=0.0, Bn=0.03, y=1.0, scale=1.0, want="all"):
+    """Gardner -> FLL -> quadrants on one burst of matched-filtered complex64."""
+    x = np.ascontiguousarray(x, dtype=np.complex64)
+    cap = x.size // sps + 8
+    if want == "all":
+        rec = np.empty(cap, np.complex128); err = np.empty(cap); mu = np.empty(cap)
+        sig = np.empty(cap, np.complex128); freq = np.empty(cap); ef = np.empty(cap)
+    else:
+        rec = err = mu = sig = freq = ef = None
+    dec = np.empty(cap, np.uint8)
+    n = lib().orc_sync_chain_c64(_p(x), x.size, float(scale), int(sps), float(alpha), float(mu0),
+                                 float(Bn), float(y), _p(rec), _p(err), _p(mu), _p(sig),
+                                 _p(freq), _p(ef), _p(dec))
+    if n < 0:
+        raise RuntimeError(f"orc_sync_chain_c64 failed ({n})")
+    if want == "all":
+        return dict(n=n, rec=rec[:n], err=err[:n - 1], mu=mu[:n - 1], sig=sig[:n],
+                    freq=freq[:n], ef=ef[:n], dec=dec[:n])
+    return dict(n=n, dec=dec[:n])
