@@ -1,0 +1,219 @@
+"""Host-side mirror of the reference's Python functions, running on the MI355X.
+
+Same names, positional order, defaults and return tuples as the reference, so a
+caller switches with an import change:
+
+    rrc_filter(sps, span, alpha)                                  read_file.py:5-36
+    gardner_timing_recovery(signal, sps, alpha=0.007, mu_initial=0.0)   gardner2.py:6-100
+    gardner_ted(x, sps, delta_mu=0.002)              hw1/gardner.py:22-74, read_file.py:53-104
+    fll_func(signal, Bn=0.001, y=1)                               fll_func.py:3-29
+    interpolate_sample(x, idx_float)                              hw1/gardner.py:8-19
+
+The single-stream functions take any complex array, run it as complex128 (what
+every reference call site passes) and return complex128 / float64 arrays.  The
+``*_batch`` forms take ``[B, N]`` arrays of independent bursts (complex64 ->
+float32 results, complex128 -> float64 results; loop arithmetic is float64 on
+the device either way) and return padded ``[B, max_n]`` arrays plus ``n_out``.
+
+All of these call libdsp_hip.so; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import DSP_C64, DSP_C128, DSP_GARDNER2, DSP_GARDNER_TED, check, default_context
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _as_bursts(x):
+    """-> contiguous [B, N] complex64 or complex128, dtype code, real dtype."""
+    x = np.asarray(x)
+    if x.ndim != 2:
+        raise ValueError("expected a [B, N] array of bursts")
+    if x.dtype == np.complex64:
+        return np.ascontiguousarray(x), DSP_C64, np.float32
+    return np.ascontiguousarray(x, dtype=np.complex128), DSP_C128, np.float64
+
+
+def _lens(lens, B, N):
+    if lens is None:
+        return None
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    if lens.shape != (B,):
+        raise ValueError("lens must have shape [B]")
+    if lens.min(initial=0) < 0 or lens.max(initial=0) > N:
+        raise ValueError("lens out of range")
+    return lens
+
+
+# ---------------------------------------------------------------------------
+# host helpers
+def rrc_filter(sps, span, alpha):
+    """Root-raised-cosine taps, unit energy (read_file.py:5-36)."""
+    L = _lib.lib()
+    n = L.dsp_rrc_taps(int(sps), int(span), float(alpha), None, 0)
+    check(n)
+    h = np.empty(n, dtype=np.float64)
+    check(L.dsp_rrc_taps(int(sps), int(span), float(alpha), _vp(h), n))
+    return h
+
+
+def fll_gains(Bn, y=1):
+    """(kp, ki) of fll_func (fll_func.py:5-6)."""
+    kp, ki = C.c_double(), C.c_double()
+    check(_lib.lib().dsp_fll_gains(float(Bn), float(y), C.byref(kp), C.byref(ki)))
+    return kp.value, ki.value
+
+
+def interpolate_sample(x, idx_float):
+    """Linear interpolation at a fractional index (hw1/gardner.py:8-19)."""
+    idx_low = int(np.floor(idx_float))
+    idx_high = idx_low + 1
+    if idx_high >= len(x):
+        return x[idx_low]
+    frac = idx_float - idx_low
+    return x[idx_low] * (1 - frac) + x[idx_high] * frac
+
+
+# ---------------------------------------------------------------------------
+# batched forms
+def gardner_batch(x, sps, alpha=0.007, mu_initial=0.0, *, variant=DSP_GARDNER2, lens=None,
+                  interp_half_len=0, capacity=None, ctx=None):
+    """Gardner timing recovery of B independent bursts.
+
+    Returns (recovered [B, cap], timing_errors [B, cap], mu_history [B, cap], n_out [B]).
+    variant DSP_GARDNER2: n_out = len(recovered) (errors/mu have n_out-1 entries);
+    variant DSP_GARDNER_TED: alpha is delta_mu and all three have n_out entries.
+    """
+    ctx = ctx or default_context()
+    x, dt, rdt = _as_bursts(x)
+    B, N = x.shape
+    sps = int(sps)
+    if sps < 1:
+        raise ValueError("sps must be >= 1")
+    lens = _lens(lens, B, N)
+    cap = int(capacity) if capacity else N // sps + 8
+    L = _lib.lib()
+    for attempt in range(2):
+        rec = np.zeros((B, cap), dtype=x.dtype)
+        err = np.zeros((B, cap), dtype=rdt)
+        mu = np.zeros((B, cap), dtype=rdt)
+        n_out = np.zeros(B, dtype=np.int32)
+        rc = L.dsp_gardner(ctx.handle, _vp(x), dt, B, N, N, _vp(lens), sps, float(alpha),
+                           float(mu_initial), int(variant), int(interp_half_len),
+                           _vp(rec), _vp(err), _vp(mu), _vp(n_out), cap)
+        if rc == _lib.DSP_E_CAPACITY and attempt == 0 and capacity is None:
+            cap *= 4          # symbol slips backwards can lengthen the output
+            continue
+        check(rc)
+        break
+    return rec, err, mu, n_out
+
+
+def fll_batch(x, Bn=0.001, y=1, *, lens=None, i0=None, state=None, want_state=False, ctx=None):
+    """fll_func on B independent symbol streams [B, M].
+
+    Returns (signal_list, curr_freq [B], curr_freq_list, ef_n_list, decisions);
+    with want_state=True also the end state [B, 2] = (curr_freq, integrator).
+    """
+    ctx = ctx or default_context()
+    x, dt, rdt = _as_bursts(x)
+    B, M = x.shape
+    lens = _lens(lens, B, M)
+    out = np.zeros((B, max(M, 1)), dtype=x.dtype)
+    freq = np.zeros((B, max(M, 1)), dtype=rdt)
+    ef = np.zeros((B, max(M, 1)), dtype=rdt)
+    dec = np.zeros((B, max(M, 1)), dtype=np.uint8)
+    st_out = np.zeros((B, 2), dtype=np.float64)
+    i0a = None if i0 is None else np.ascontiguousarray(np.broadcast_to(i0, (B,)), dtype=np.float64)
+    sta = None if state is None else np.ascontiguousarray(state, dtype=np.float64).reshape(B, 2)
+    if B and M:
+        check(_lib.lib().dsp_fll(ctx.handle, _vp(x), dt, B, _vp(lens), M, M, float(Bn), float(y),
+                                 _vp(i0a), _vp(sta), _vp(st_out), _vp(out), _vp(freq), _vp(ef),
+                                 _vp(dec), max(M, 1)))
+    elif sta is not None:
+        st_out[:] = sta
+    res = (out[:, :M], st_out[:, 0].copy(), freq[:, :M], ef[:, :M], dec[:, :M])
+    return res + (st_out,) if want_state else res
+
+
+def sync_chain_batch(x, sps=4, alpha=0.007, mu_initial=0.0, Bn=0.03, y=1, *, variant=DSP_GARDNER2,
+                     lens=None, scale=None, interp_half_len=0, outputs="all", capacity=None, ctx=None):
+    """Fused Gardner -> FLL -> hard decisions (worker.py:301-304) on matched-filtered bursts.
+
+    outputs: "all" or an iterable out of {"rec","err","mu","sig","freq","ef","dec"}.
+    Returns a dict with the requested [B, cap] arrays and "n_out" [B].
+    """
+    ctx = ctx or default_context()
+    x, dt, rdt = _as_bursts(x)
+    B, N = x.shape
+    sps = int(sps)
+    lens = _lens(lens, B, N)
+    names = ("rec", "err", "mu", "sig", "freq", "ef", "dec") if outputs == "all" else tuple(outputs)
+    cap = int(capacity) if capacity else N // sps + 8
+    sc = None if scale is None else np.ascontiguousarray(np.broadcast_to(scale, (B,)), dtype=np.float64)
+    L = _lib.lib()
+    for attempt in range(2):
+        bufs = {}
+        for nm in names:
+            dtp = x.dtype if nm in ("rec", "sig") else (np.uint8 if nm == "dec" else rdt)
+            bufs[nm] = np.zeros((B, cap), dtype=dtp)
+        n_out = np.zeros(B, dtype=np.int32)
+        g = lambda nm: _vp(bufs.get(nm))  # noqa: E731
+        rc = L.dsp_sync_chain(ctx.handle, _vp(x), dt, B, N, N, _vp(lens), _vp(sc), sps, float(alpha),
+                              float(mu_initial), int(variant), int(interp_half_len), float(Bn),
+                              float(y), g("rec"), g("err"), g("mu"), g("sig"), g("freq"), g("ef"),
+                              g("dec"), _vp(n_out), cap)
+        if rc == _lib.DSP_E_CAPACITY and attempt == 0 and capacity is None:
+            cap *= 4
+            continue
+        check(rc)
+        break
+    bufs["n_out"] = n_out
+    return bufs
+
+
+# ---------------------------------------------------------------------------
+# the reference's single-stream signatures
+def gardner_timing_recovery(signal, sps, alpha=0.007, mu_initial=0.0):
+    """Drop-in for gardner2.gardner_timing_recovery (gardner2.py:6-100)."""
+    x = np.asarray(signal)
+    if x.ndim != 1:
+        raise ValueError("signal must be one-dimensional")
+    if x.size == 0:
+        raise IndexError("index 0 is out of bounds for axis 0 with size 0")   # gardner2.py:59
+    x = x.astype(np.complex128, copy=False)
+    rec, err, mu, n = gardner_batch(x[None, :], sps, alpha, mu_initial, variant=DSP_GARDNER2)
+    n = int(n[0])
+    return rec[0, :n].copy(), err[0, :n - 1].copy(), mu[0, :n - 1].copy()
+
+
+def gardner_ted(x, sps, delta_mu=0.002):
+    """Drop-in for gardner_ted (hw1/gardner.py:22-74; delta_mu as in read_file.py:53)."""
+    x = np.asarray(x)
+    if x.ndim != 1:
+        raise ValueError("x must be one-dimensional")
+    if x.size == 0:
+        return np.array([]), np.array([]), np.array([])
+    x = x.astype(np.complex128, copy=False)
+    y, err, mu, n = gardner_batch(x[None, :], sps, delta_mu, 0.0, variant=DSP_GARDNER_TED)
+    n = int(n[0])
+    return y[0, :n].copy(), err[0, :n].copy(), mu[0, :n].copy()
+
+
+def fll_func(signal, Bn=0.001, y=1):
+    """Drop-in for fll_func.fll_func (fll_func.py:3-29)."""
+    x = np.asarray(signal)
+    if x.ndim != 1:
+        raise ValueError("signal must be one-dimensional")
+    if x.size == 0:
+        return np.zeros(0, dtype=complex), 0, np.zeros(0, dtype=float), np.zeros(0, dtype=float)
+    x = x.astype(np.complex128, copy=False)
+    out, cf, freq, ef, _ = fll_batch(x[None, :], Bn, y)
+    return out[0].copy(), float(cf[0]), freq[0].copy(), ef[0].copy()

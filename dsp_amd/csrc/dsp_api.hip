@@ -1,0 +1,476 @@
+// dsp_api.hip -- the C ABI of libdsp_hip.so (include/dsp_hip.h): context,
+// device memory, and the host-side orchestration of the kernels.  No C++
+// exception crosses the boundary; every entry point returns a status code.
+#include "../../include/dsp_hip.h"
+#include "dsp_internal.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+struct dsp_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    hipEvent_t ev0, ev1;
+    int ring_rows;      // 0 = automatic
+    int lds_pad;        // extra dynamic LDS per workgroup (bytes) to steer workgroups per CU
+};
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(DSP_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
+                        __FILE__, __LINE__);                                                \
+    } while (0)
+
+// RAII device buffer for the host-pointer entry points
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
+    template <typename T> T *as() { return (T *)p; }
+};
+
+extern "C" {
+
+int dsp_version(void) { return 100; }
+const char *dsp_last_error(void) { return g_err; }
+
+int dsp_device_count(int *count)
+{
+    if (!count) return fail(DSP_E_ARG, "count is NULL");
+    HIP_TRY(hipGetDeviceCount(count));
+    return DSP_OK;
+}
+
+int dsp_create(int device_id, dsp_ctx **out)
+{
+    if (!out) return fail(DSP_E_ARG, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device_id < 0 || device_id >= n)
+        return fail(DSP_E_ARG, "device %d not available (%d HIP devices visible)", device_id, n);
+    HIP_TRY(hipSetDevice(device_id));
+    dsp_ctx *c = new dsp_ctx();
+    c->device = device_id;
+    c->own_stream = true;
+    c->ring_rows = 0;
+    c->lds_pad = -1;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(DSP_E_HIP, "context creation failed: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return DSP_OK;
+}
+
+void dsp_destroy(dsp_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipEventDestroy(c->ev0);
+    (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int dsp_set_stream(dsp_ctx *c, void *s)
+{
+    if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    c->stream = (hipStream_t)s;
+    c->own_stream = false;
+    return DSP_OK;
+}
+
+int dsp_synchronize(dsp_ctx *c)
+{
+    if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DSP_OK;
+}
+
+int dsp_set_option(dsp_ctx *c, const char *name, int64_t value)
+{
+    if (!c || !name) return fail(DSP_E_ARG, "ctx/name is NULL");
+    if (!strcmp(name, "ring_rows")) {
+        if (value != 0 && (value < 16 || value > 256 || (value & (value - 1))))
+            return fail(DSP_E_ARG, "ring_rows must be 0 or a power of two in [16,256]");
+        c->ring_rows = (int)value;
+    } else if (!strcmp(name, "lds_pad")) {
+        c->lds_pad = (int)value;
+    } else {
+        return fail(DSP_E_ARG, "unknown option '%s'", name);
+    }
+    return DSP_OK;
+}
+
+int dsp_malloc(dsp_ctx *c, size_t bytes, void **dptr)
+{
+    if (!c || !dptr) return fail(DSP_E_ARG, "ctx/dptr is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 16);
+    if (e != hipSuccess) return fail(DSP_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return DSP_OK;
+}
+int dsp_free(dsp_ctx *c, void *dptr)
+{
+    if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    if (dptr) HIP_TRY(hipFree(dptr));
+    return DSP_OK;
+}
+int dsp_memset(dsp_ctx *c, void *dptr, int value, size_t bytes)
+{
+    if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    HIP_TRY(hipMemsetAsync(dptr, value, bytes, c->stream));
+    return DSP_OK;
+}
+int dsp_h2d(dsp_ctx *c, void *dptr, const void *hptr, size_t bytes)
+{
+    if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    HIP_TRY(hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DSP_OK;
+}
+int dsp_d2h(dsp_ctx *c, void *hptr, const void *dptr, size_t bytes)
+{
+    if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    HIP_TRY(hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DSP_OK;
+}
+int dsp_timer_start(dsp_ctx *c)
+{
+    if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    return DSP_OK;
+}
+int dsp_timer_stop(dsp_ctx *c, float *ms)
+{
+    if (!c || !ms) return fail(DSP_E_ARG, "ctx/ms is NULL");
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return DSP_OK;
+}
+
+// ---------------------------------------------------------------------------
+static int64_t floordiv64(int64_t a, int64_t b)
+{
+    int64_t q = a / b;
+    if ((a % b != 0) && ((a < 0) != (b < 0))) q--;
+    return q;
+}
+
+// rrc_filter -- read_file.py:5-36.  Same expression tree as the reference,
+// evaluated in float64 with the host libm.
+int dsp_rrc_taps(int sps, int span, double alpha, double *h, int64_t n_taps)
+{
+    if (sps <= 0 || span <= 0 || !(alpha > 0.0)) return fail(DSP_E_ARG, "rrc_taps: bad sps/span/alpha");
+    int64_t lo = floordiv64(-(int64_t)span * sps, 2);
+    int64_t n = floordiv64((int64_t)span * sps, 2) + 1 - lo;
+    if (!h) return (int)n;
+    if (n_taps != n) return fail(DSP_E_ARG, "rrc_taps: n_taps must be %lld", (long long)n);
+    const double pi = 3.141592653589793;
+    double ss = 0.0;
+    for (int64_t i = 0; i < n; i++) {
+        int64_t ti = lo + i;
+        double t = (double)ti;
+        double v;
+        if (ti == 0) {
+            v = 1 + alpha * (4 / pi - 1);
+        } else if (fabs(t) == sps / (4 * alpha)) {
+            v = (alpha / sqrt(2.0)) *
+                ((1 + 2 / pi) * sin(pi / (4 * alpha)) + (1 - 2 / pi) * cos(pi / (4 * alpha)));
+        } else {
+            double a = pi * t / sps;
+            double q = 4 * alpha * t / sps;
+            v = (sin(a * (1 - alpha)) + q * cos(a * (1 + alpha))) / (a * (1 - q * q));
+        }
+        h[i] = v;
+    }
+    // unit energy: h / sqrt(sum h^2).  Summed pairwise in blocks of 8 like the
+    // reference's np.sum so short filters normalise to the same bits.
+    {
+        std::vector<double> sq((size_t)n);
+        for (int64_t i = 0; i < n; i++) sq[(size_t)i] = h[i] * h[i];
+        struct PW {
+            static double run(const double *a, int64_t m)
+            {
+                if (m < 8) { double r = 0.0; for (int64_t i = 0; i < m; i++) r += a[i]; return r; }
+                if (m <= 128) {
+                    double r[8]; int64_t i;
+                    for (int j = 0; j < 8; j++) r[j] = a[j];
+                    for (i = 8; i < m - (m % 8); i += 8) for (int j = 0; j < 8; j++) r[j] += a[i + j];
+                    double s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+                    for (; i < m; i++) s += a[i];
+                    return s;
+                }
+                int64_t m2 = m / 2; m2 -= m2 % 8;
+                return run(a, m2) + run(a + m2, m - m2);
+            }
+        };
+        ss = PW::run(sq.data(), n);
+    }
+    double nrm = sqrt(ss);
+    for (int64_t i = 0; i < n; i++) h[i] = h[i] / nrm;
+    return DSP_OK;
+}
+
+int dsp_fll_gains(double Bn, double y, double *kp, double *ki)
+{
+    if (!kp || !ki) return fail(DSP_E_ARG, "kp/ki is NULL");
+    double d = y + 1 / (4 * y);
+    *kp = 4 * Bn / 1000 / d;                  // fll_func.py:5
+    double q = Bn / 1000 / d;
+    *ki = 4 * pow(q, 2.0);                    // fll_func.py:6
+    return DSP_OK;
+}
+
+int64_t dsp_tile_rows(int64_t N) { return N <= 0 ? 2 : ((N + 1) / 2) * 2; }
+
+// ---------------------------------------------------------------------------
+static int count_nonnull(std::initializer_list<const void *> l)
+{
+    int n = 0;
+    for (const void *p : l) n += p ? 1 : 0;
+    return n;
+}
+
+int dsp_sync_tiles_dev(dsp_ctx *c, const dsp_sync_args *a)
+{
+    if (!c || !a) return fail(DSP_E_ARG, "ctx/args is NULL");
+    if (a->B < 0 || a->B > (1 << 30)) return fail(DSP_E_ARG, "sync: bad B");
+    if (a->B == 0) return DSP_OK;
+    if (!a->x) return fail(DSP_E_ARG, "sync: x is NULL");
+    if (a->dtype != DSP_C64 && a->dtype != DSP_C128) return fail(DSP_E_ARG, "sync: bad dtype");
+    if (a->variant < 0 || a->variant > 2) return fail(DSP_E_ARG, "sync: bad variant");
+    const bool fll = a->do_fll != 0 || a->variant == 2;
+    const int sps = a->variant == 2 ? 1 : a->sps;
+    if (sps < 1 || sps > 1024) return fail(DSP_E_ARG, "sync: sps out of range");
+    if (a->N < 0 || a->N >= (1LL << 30)) return fail(DSP_E_ARG, "sync: N out of range");
+    if (a->in_rows < a->N || a->in_rows < 2 || (a->in_rows & 1))
+        return fail(DSP_E_ARG, "sync: in_rows must be even and >= N (use dsp_tile_rows)");
+    if (a->out_rows < 1 || a->out_rows >= (1LL << 30)) return fail(DSP_E_ARG, "sync: bad out_rows");
+    if (a->interp_half_len < 0 || a->interp_half_len > 8)
+        return fail(DSP_E_ARG, "sync: interp_half_len must be in [0,8]");
+    if (fll && !(a->y > 0.0)) return fail(DSP_E_ARG, "sync: y must be > 0");
+
+    SyncParams P;
+    memset(&P, 0, sizeof(P));
+    P.x = a->x; P.lens = a->lens; P.scale = a->scale;
+    P.B = (int)a->B; P.in_rows = (int)a->in_rows; P.len_all = (int)a->N; P.sps = sps;
+    P.alpha = a->alpha; P.mu0 = a->mu0; P.half_len = a->variant == 2 ? 0 : a->interp_half_len;
+    if (fll) dsp_fll_gains(a->Bn, a->y, &P.kp, &P.ki);
+    P.i0 = a->i0; P.fll_in = a->fll_state_in; P.fll_out = a->fll_state_out;
+    P.rec = a->variant == 2 ? nullptr : a->rec;
+    P.terr = a->variant == 2 ? nullptr : a->err;
+    P.mu = a->variant == 2 ? nullptr : a->mu;
+    P.sig = fll ? a->sig : nullptr; P.freq = fll ? a->freq : nullptr; P.ef = fll ? a->ef : nullptr;
+    P.dec = fll ? a->dec : nullptr;
+    P.out_rows = (int)a->out_rows; P.n_out = a->n_out; P.status = a->status;
+
+    int n_store = count_nonnull({P.rec, P.terr, P.mu, P.sig, P.freq, P.ef, P.dec});
+    int elem = a->dtype == DSP_C128 ? 16 : 8;
+    int R = c->ring_rows;
+    if (R == 0) R = (sps > 8 || P.half_len > 2) ? 128 : 64;
+    if (R * 64 * elem > 64 * 1024) R = 64 * 1024 / (64 * elem);
+    SyncPlan pl = sync_plan(elem, sps, P.half_len, a->variant, n_store, R);
+    P.use_ring = pl.use_ring; P.ring_rows = pl.ring_rows; P.T = pl.T; P.C = pl.C; P.nwait = pl.nwait;
+
+    // Dynamic LDS also steers residency: one wave per workgroup, so workgroups per
+    // CU = floor(160 KiB / lds).  By default spread the tiles evenly over 256 CUs.
+    size_t lds = (size_t)pl.lds_bytes;
+    int ntiles = (P.B + 63) / 64;
+    if (c->lds_pad >= 0) {
+        lds += (size_t)c->lds_pad;
+    } else {
+        int per_cu = (ntiles + 255) / 256;
+        if (per_cu < 1) per_cu = 1;
+        size_t even = ((size_t)160 * 1024 / per_cu) & ~(size_t)1023;
+        if (even > 64 * 1024) even = 64 * 1024;
+        if (even > lds) lds = even;
+    }
+    if (lds > 64 * 1024) lds = 64 * 1024;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_sync(P, a->dtype == DSP_C128, a->variant, fll, lds, c->stream));
+    return DSP_OK;
+}
+
+int dsp_tile_bursts_dev(dsp_ctx *c, const void *d_src, int dtype, int64_t B, int64_t N,
+                        int64_t src_stride, const int32_t *d_lens, void *d_tiles, int64_t rows)
+{
+    if (!c || !d_src || !d_tiles) return fail(DSP_E_ARG, "tile: NULL argument");
+    if (rows < N || B < 0) return fail(DSP_E_ARG, "tile: rows < N");
+    HIP_TRY(launch_tile_from_bursts(d_src, src_stride, d_lens, (int)N, (int)B, d_tiles, (int)rows,
+                                    dtype == DSP_C128 ? 16 : 8, c->stream));
+    return DSP_OK;
+}
+
+int dsp_untile_dev(dsp_ctx *c, const void *d_tiles, int elem_bytes, int64_t rows, int64_t B,
+                   void *d_dst, int64_t dst_stride, int64_t ncopy)
+{
+    if (!c || !d_tiles || !d_dst) return fail(DSP_E_ARG, "untile: NULL argument");
+    if (ncopy > rows) ncopy = rows;
+    HIP_TRY(launch_bursts_from_tiles(d_tiles, (int)rows, (int)B, d_dst, dst_stride, (int)ncopy,
+                                     elem_bytes, c->stream));
+    return DSP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Host-pointer orchestration shared by dsp_gardner / dsp_fll / dsp_sync_chain.
+struct HostOut { void *h; int elem; };
+
+static int run_host(dsp_ctx *c, const void *x, int dtype, int64_t B, int64_t N, int64_t x_stride,
+                    const int32_t *lens, const double *scale, int sps, double alpha, double mu0,
+                    int variant, int half_len, bool fll, double Bn, double y, const double *i0,
+                    const double *st_in, double *st_out, void *rec, void *err, void *mu, void *sig,
+                    void *freq, void *ef, uint8_t *dec, int32_t *n_out, int64_t out_stride)
+{
+    if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    if (B < 0 || N < 0) return fail(DSP_E_ARG, "negative B or N");
+    if (B == 0) return DSP_OK;
+    if (!x) return fail(DSP_E_ARG, "x is NULL");
+    if (x_stride < N) return fail(DSP_E_ARG, "x_stride < N");
+    if (out_stride < 1) return fail(DSP_E_ARG, "out_stride < 1");
+    if (lens)
+        for (int64_t b = 0; b < B; b++)
+            if (lens[b] < 0 || lens[b] > N) return fail(DSP_E_ARG, "lens[%lld] out of range", (long long)b);
+    HIP_TRY(hipSetDevice(c->device));
+    const int ce = dtype == DSP_C128 ? 16 : 8, re = ce / 2;
+    const int64_t rows = dsp_tile_rows(N);
+    const int64_t ntiles = (B + 63) / 64;
+    const int64_t out_rows = out_stride;
+    hipStream_t s = c->stream;
+
+    DevBuf d_x, d_xt, d_lens, d_scale, d_i0, d_stin, d_stout, d_nout, d_status, d_stage;
+    HIP_TRY(d_x.alloc((size_t)B * x_stride * ce));
+    HIP_TRY(d_xt.alloc((size_t)ntiles * rows * 64 * ce));
+    HIP_TRY(hipMemcpyAsync(d_x.p, x, (size_t)B * x_stride * ce, hipMemcpyHostToDevice, s));
+    if (lens) {
+        HIP_TRY(d_lens.alloc((size_t)B * 4));
+        HIP_TRY(hipMemcpyAsync(d_lens.p, lens, (size_t)B * 4, hipMemcpyHostToDevice, s));
+    }
+    if (scale) {
+        HIP_TRY(d_scale.alloc((size_t)B * 8));
+        HIP_TRY(hipMemcpyAsync(d_scale.p, scale, (size_t)B * 8, hipMemcpyHostToDevice, s));
+    }
+    if (i0) {
+        HIP_TRY(d_i0.alloc((size_t)B * 8));
+        HIP_TRY(hipMemcpyAsync(d_i0.p, i0, (size_t)B * 8, hipMemcpyHostToDevice, s));
+    }
+    if (st_in) {
+        HIP_TRY(d_stin.alloc((size_t)B * 16));
+        HIP_TRY(hipMemcpyAsync(d_stin.p, st_in, (size_t)B * 16, hipMemcpyHostToDevice, s));
+    }
+    if (st_out) HIP_TRY(d_stout.alloc((size_t)B * 16));
+    HIP_TRY(d_nout.alloc((size_t)B * 4));
+    HIP_TRY(d_status.alloc((size_t)B * 4));
+    HIP_TRY(launch_tile_from_bursts(d_x.p, x_stride, d_lens.as<int>(), (int)N, (int)B, d_xt.p, (int)rows,
+                                    ce, s));
+
+    struct OutSpec { void *host; int elem; DevBuf tiles; };
+    OutSpec outs[7] = {{rec, ce, {}}, {err, re, {}}, {mu, re, {}}, {sig, ce, {}},
+                       {freq, re, {}}, {ef, re, {}}, {(void *)dec, 1, {}}};
+    size_t max_elem = 1;
+    for (auto &o : outs)
+        if (o.host) {
+            HIP_TRY(o.tiles.alloc((size_t)ntiles * out_rows * 64 * o.elem));
+            if ((size_t)o.elem > max_elem) max_elem = o.elem;
+        }
+
+    dsp_sync_args a;
+    memset(&a, 0, sizeof(a));
+    a.x = d_xt.p; a.dtype = dtype; a.variant = variant; a.B = B; a.N = N; a.in_rows = rows;
+    a.lens = d_lens.as<int32_t>(); a.scale = d_scale.as<double>();
+    a.sps = sps; a.interp_half_len = half_len; a.alpha = alpha; a.mu0 = mu0;
+    a.do_fll = fll ? 1 : 0; a.Bn = Bn; a.y = y;
+    a.i0 = d_i0.as<double>(); a.fll_state_in = d_stin.as<double>(); a.fll_state_out = d_stout.as<double>();
+    a.rec = outs[0].tiles.p; a.err = outs[1].tiles.p; a.mu = outs[2].tiles.p; a.sig = outs[3].tiles.p;
+    a.freq = outs[4].tiles.p; a.ef = outs[5].tiles.p; a.dec = (uint8_t *)outs[6].tiles.p;
+    a.out_rows = out_rows; a.n_out = d_nout.as<int32_t>(); a.status = d_status.as<int32_t>();
+    int rc = dsp_sync_tiles_dev(c, &a);
+    if (rc != DSP_OK) return rc;
+
+    // tiles -> burst-major staging -> host
+    HIP_TRY(d_stage.alloc((size_t)B * out_stride * max_elem));
+    for (auto &o : outs) {
+        if (!o.host) continue;
+        HIP_TRY(launch_bursts_from_tiles(o.tiles.p, (int)out_rows, (int)B, d_stage.p, out_stride,
+                                         (int)out_rows, o.elem, s));
+        HIP_TRY(hipMemcpyAsync(o.host, d_stage.p, (size_t)B * out_stride * o.elem,
+                               hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    std::vector<int32_t> status((size_t)B);
+    std::vector<int32_t> nout_tmp;
+    int32_t *nout_h = n_out;
+    if (!nout_h) { nout_tmp.resize((size_t)B); nout_h = nout_tmp.data(); }
+    HIP_TRY(hipMemcpyAsync(nout_h, d_nout.p, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(status.data(), d_status.p, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+    if (st_out) HIP_TRY(hipMemcpyAsync(st_out, d_stout.p, (size_t)B * 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int64_t b = 0; b < B; b++)
+        if (status[(size_t)b] & 1)
+            return fail(DSP_E_CAPACITY, "burst %lld: out_stride %lld too small (loop still running "
+                        "after %d symbols)", (long long)b, (long long)out_stride, nout_h[b]);
+    return DSP_OK;
+}
+
+int dsp_gardner(dsp_ctx *c, const void *x, int dtype, int64_t B, int64_t N, int64_t x_stride,
+                const int32_t *lens, int sps, double alpha, double mu0, int variant,
+                int interp_half_len, void *rec, void *err, void *mu, int32_t *n_out,
+                int64_t out_stride)
+{
+    if (variant != DSP_GARDNER2 && variant != DSP_GARDNER_TED) return fail(DSP_E_ARG, "gardner: bad variant");
+    if (sps < 1) return fail(DSP_E_ARG, "gardner: sps must be >= 1");
+    return run_host(c, x, dtype, B, N, x_stride, lens, nullptr, sps, alpha, mu0, variant,
+                    interp_half_len, false, 0.0, 1.0, nullptr, nullptr, nullptr, rec, err, mu,
+                    nullptr, nullptr, nullptr, nullptr, n_out, out_stride);
+}
+
+int dsp_fll(dsp_ctx *c, const void *x, int dtype, int64_t B, const int32_t *M, int64_t M_max,
+            int64_t x_stride, double Bn, double y, const double *i0, const double *state_in,
+            double *state_out, void *out, void *freq, void *ef, uint8_t *dec, int64_t out_stride)
+{
+    if (out_stride < M_max) return fail(DSP_E_ARG, "fll: out_stride < M_max");
+    return run_host(c, x, dtype, B, M_max, x_stride, M, nullptr, 1, 0.0, 0.0, 2, 0, true, Bn, y, i0,
+                    state_in, state_out, nullptr, nullptr, nullptr, out, freq, ef, dec, nullptr,
+                    out_stride);
+}
+
+int dsp_sync_chain(dsp_ctx *c, const void *x, int dtype, int64_t B, int64_t N, int64_t x_stride,
+                   const int32_t *lens, const double *scale, int sps, double alpha, double mu0,
+                   int variant, int interp_half_len, double Bn, double y,
+                   void *rec, void *err, void *mu, void *sig, void *freq, void *ef, uint8_t *dec,
+                   int32_t *n_out, int64_t out_stride)
+{
+    if (variant != DSP_GARDNER2 && variant != DSP_GARDNER_TED) return fail(DSP_E_ARG, "chain: bad variant");
+    if (sps < 1) return fail(DSP_E_ARG, "chain: sps must be >= 1");
+    return run_host(c, x, dtype, B, N, x_stride, lens, scale, sps, alpha, mu0, variant,
+                    interp_half_len, true, Bn, y, nullptr, nullptr, nullptr, rec, err, mu, sig, freq,
+                    ef, dec, n_out, out_stride);
+}
+
+}  // extern "C"

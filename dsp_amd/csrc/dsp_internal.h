@@ -1,0 +1,56 @@
+// dsp_internal.h -- declarations shared between the C-ABI layer (dsp_api.hip)
+// and the kernel translation units.  Not installed; the public surface is
+// include/dsp_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+// ---------------------------------------------------------------------------
+// Device data layout ("tiles"): bursts are grouped 64 to a tile, one burst per
+// wavefront lane.  Element (burst b, row n) of a tiled array lives at
+//     ((b / 64) * rows + n) * 64 + (b % 64)
+// so a wavefront that walks its tile row by row reads/writes one contiguous
+// 64-element row per step (512 B for complex64) and a tile is one contiguous
+// stream of rows * 64 elements.  Input tiles have `rows` even, padded with zeros.
+// ---------------------------------------------------------------------------
+
+enum { DSP_VARIANT_GARDNER2 = 0, DSP_VARIANT_TED = 1, DSP_VARIANT_NONE = 2 };
+
+struct SyncParams {
+    // input
+    const void *x;            // tiled [ntiles][in_rows][64] complex64 or complex128
+    const int *lens;          // [B] valid samples per burst, or NULL -> len_all
+    const double *scale;      // [B] per-burst input scale (1/std), or NULL -> 1.0
+    int B, in_rows, len_all, sps;
+    // Gardner
+    double alpha;             // gardner2: alpha; ted: delta_mu
+    double mu0;
+    int half_len;             // 0 = linear interpolation
+    // FLL
+    double kp, ki;
+    const double *i0;         // [B] absolute index of the first FLL symbol, or NULL -> 0
+    const double *fll_in;     // [B][2] {curr_freq, integrator} start state, or NULL -> 0
+    double *fll_out;          // [B][2] end state, or NULL
+    // outputs, tiled [ntiles][out_rows][64]; any may be NULL
+    void *rec, *terr, *mu, *sig, *freq, *ef;
+    uint8_t *dec;
+    int out_rows;
+    int *n_out;               // [B] number of symbols produced
+    int *status;              // [B] bit0: output capacity reached before the loop ended
+    // LDS ring schedule (host-computed, see sync_plan())
+    int use_ring, ring_rows, T, C, nwait;
+};
+
+struct SyncPlan { int use_ring, ring_rows, T, C, nwait, lds_bytes; };
+
+// host helpers implemented next to the kernels
+SyncPlan sync_plan(int elem_bytes, int sps, int half_len, int variant, int n_store, int ring_rows_req);
+hipError_t launch_sync(const SyncParams &P, bool c128, int variant, bool fll, size_t lds_bytes,
+                       hipStream_t stream);
+
+// tiling: burst-major [B][ld] <-> tiles
+hipError_t launch_tile_from_bursts(const void *src, int64_t ld, const int *lens, int len_all, int B,
+                                   void *dst, int rows, int elem_bytes, hipStream_t stream);
+hipError_t launch_bursts_from_tiles(const void *src, int rows, int B, void *dst, int64_t ld,
+                                    int ncopy, int elem_bytes, hipStream_t stream);

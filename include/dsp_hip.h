@@ -1,0 +1,143 @@
+/*
+ * dsp_hip.h -- C ABI of libdsp_hip.so: the MI355X (gfx950) implementation of the
+ * QPSK receiver synchronisation chain of boryaska/dsp (RRC matched filter ->
+ * Gardner timing recovery -> decision-directed FLL -> hard decisions, plus the
+ * raw IQ loaders that feed it).
+ *
+ * The reference has no FFI: its boundary is a set of Python functions imported
+ * by name.  Each entry point below names the reference function
+ * (file:line) whose arithmetic it reproduces; dsp_amd/api.py binds them with
+ * ctypes behind the reference's own function signatures.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (DSP_E_*); the message is
+ *     available from dsp_last_error() (thread-local);
+ *   - complex64 is interleaved float[2], complex128 interleaved double[2];
+ *     `dtype` selects the sample type of the call: DSP_C64 -> float32 outputs,
+ *     DSP_C128 -> float64 outputs (what the reference's numpy code returns);
+ *   - all loop arithmetic is float64 on the device in both cases;
+ *   - host-pointer entry points take burst-major arrays [B][stride] (one burst
+ *     per row); the library never keeps a host pointer after it returns;
+ *   - *_dev entry points take device pointers in the tiled layout: element
+ *     (burst b, row n) at ((b/64)*rows + n)*64 + b%64 -- 64 bursts per tile, one
+ *     burst per wavefront lane.  Rows >= n_out[b] of an output hold zeros;
+ *   - one dsp_ctx = one HIP device + one stream; calls on a context are
+ *     serialised by the caller; use one context (one process) per GPU.
+ */
+#ifndef DSP_HIP_H
+#define DSP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dsp_ctx dsp_ctx;
+
+enum { DSP_OK = 0, DSP_E_ARG = -1, DSP_E_HIP = -2, DSP_E_CAPACITY = -3, DSP_E_NOMEM = -4 };
+enum { DSP_C64 = 0, DSP_C128 = 1 };
+enum { DSP_GARDNER2 = 0,   /* gardner_timing_recovery, gardner2.py:6-100          */
+       DSP_GARDNER_TED = 1 /* gardner_ted, hw1/gardner.py:22-74, read_file.py:53-104 */ };
+
+/* ---- context ------------------------------------------------------------- */
+int dsp_version(void);
+int dsp_device_count(int *count);
+int dsp_create(int device_id, dsp_ctx **out);
+void dsp_destroy(dsp_ctx *ctx);
+const char *dsp_last_error(void);
+int dsp_set_stream(dsp_ctx *ctx, void *hip_stream);      /* adopt an external hipStream_t */
+int dsp_synchronize(dsp_ctx *ctx);
+int dsp_set_option(dsp_ctx *ctx, const char *name, int64_t value); /* "ring_rows", "lds_pad" */
+
+/* ---- device memory and timing (for *_dev pipelines and bench.py) ---------- */
+int dsp_malloc(dsp_ctx *ctx, size_t bytes, void **dptr);
+int dsp_free(dsp_ctx *ctx, void *dptr);
+int dsp_memset(dsp_ctx *ctx, void *dptr, int value, size_t bytes);
+int dsp_h2d(dsp_ctx *ctx, void *dptr, const void *hptr, size_t bytes);
+int dsp_d2h(dsp_ctx *ctx, void *hptr, const void *dptr, size_t bytes);
+int dsp_timer_start(dsp_ctx *ctx);                       /* hipEvent on the context stream */
+int dsp_timer_stop(dsp_ctx *ctx, float *elapsed_ms);     /* records, synchronises, returns */
+
+/* ---- host-side helpers (no GPU needed) ------------------------------------ */
+/* rrc_filter(sps, span, alpha) -- read_file.py:5-36 (= diff_method.py:8-39).
+ * Writes n_taps = span*sps//2 + 1 - (-span*sps//2) taps; returns the count when
+ * h is NULL.                                                                   */
+int dsp_rrc_taps(int sps, int span, double alpha, double *h, int64_t n_taps);
+/* kp, ki of fll_func -- fll_func.py:5-6.                                       */
+int dsp_fll_gains(double Bn, double y, double *kp, double *ki);
+/* rows a tiled input buffer needs for bursts of N samples (even, >= N).        */
+int64_t dsp_tile_rows(int64_t N);
+
+/* ---- host-pointer, burst-major entry points ------------------------------- */
+/* Gardner timing recovery for B independent bursts (a3-a5, a9).
+ *   variant DSP_GARDNER2:    gardner_timing_recovery(x, sps, alpha, mu0)  gardner2.py:6-100
+ *           DSP_GARDNER_TED: gardner_ted(x, sps, delta_mu = alpha)        hw1/gardner.py:22-74
+ *   interp_half_len 0 = the reference's linear interpolation; h > 0 = (2h+1)-point
+ *   Lagrange (hw1/test_lagrange_resampling.py:34-72) inside the loop (extension).
+ *   lens: per-burst sample counts (NULL = all N).  Outputs [B][out_stride]
+ *   (NULL = not wanted): rec has n_out[b] entries, err and mu n_out[b]-1
+ *   (GARDNER2) or n_out[b] (TED).  Returns DSP_E_CAPACITY if out_stride was
+ *   too small for some burst (outputs up to the capacity are valid).           */
+int dsp_gardner(dsp_ctx *ctx, const void *x, int dtype, int64_t B, int64_t N, int64_t x_stride,
+                const int32_t *lens, int sps, double alpha, double mu0, int variant,
+                int interp_half_len, void *rec, void *err, void *mu, int32_t *n_out,
+                int64_t out_stride);
+
+/* fll_func(signal, Bn, y) for B independent symbol streams (a6, a7) --
+ * fll_func.py:3-29.  M: per-stream symbol counts (NULL = all M_max).
+ * i0 / state_in / state_out (NULL = reference behaviour: index 0, zero state)
+ * continue a loop at absolute index i0[b] from {curr_freq, integrator}.
+ * Outputs [B][out_stride]: out = signal_list, freq = curr_freq_list,
+ * ef = ef_n_list, dec = quadrant (Re<0) + 2*(Im<0) of signal_list.             */
+int dsp_fll(dsp_ctx *ctx, const void *x, int dtype, int64_t B, const int32_t *M, int64_t M_max,
+            int64_t x_stride, double Bn, double y, const double *i0, const double *state_in,
+            double *state_out, void *out, void *freq, void *ef, uint8_t *dec, int64_t out_stride);
+
+/* The fused chain of worker.py:301-304 on matched-filtered bursts: Gardner
+ * (variant) -> fll_func -> decisions in ONE kernel; the recovered symbols never
+ * leave the chip.  scale: optional per-burst factor applied to every input
+ * sample first (the 1/np.std of worker.py:177), NULL = 1.                      */
+int dsp_sync_chain(dsp_ctx *ctx, const void *x, int dtype, int64_t B, int64_t N, int64_t x_stride,
+                   const int32_t *lens, const double *scale, int sps, double alpha, double mu0,
+                   int variant, int interp_half_len, double Bn, double y,
+                   void *rec, void *err, void *mu, void *sig, void *freq, void *ef, uint8_t *dec,
+                   int32_t *n_out, int64_t out_stride);
+
+/* ---- device-resident tiled entry points ------------------------------------ */
+/* burst-major device array -> tiles (zero padded); rows = dsp_tile_rows(N).     */
+int dsp_tile_bursts_dev(dsp_ctx *ctx, const void *d_src, int dtype, int64_t B, int64_t N,
+                        int64_t src_stride, const int32_t *d_lens, void *d_tiles, int64_t rows);
+/* tiles -> burst-major device array, first ncopy rows; elem_bytes in {1,4,8,16} */
+int dsp_untile_dev(dsp_ctx *ctx, const void *d_tiles, int elem_bytes, int64_t rows, int64_t B,
+                   void *d_dst, int64_t dst_stride, int64_t ncopy);
+
+typedef struct dsp_sync_args {
+    const void *x;          /* tiles [ceil(B/64)][in_rows][64], dtype samples        */
+    int32_t dtype;          /* DSP_C64 / DSP_C128                                    */
+    int32_t variant;        /* DSP_GARDNER2 / DSP_GARDNER_TED / 2 = FLL only (1 sps) */
+    int64_t B, N, in_rows;  /* bursts, samples per burst (max), rows of x            */
+    const int32_t *lens;    /* [B] or NULL                                           */
+    const double *scale;    /* [B] or NULL                                           */
+    int32_t sps, interp_half_len;
+    double alpha, mu0;
+    int32_t do_fll, reserved;
+    double Bn, y;
+    const double *i0;       /* [B] or NULL                                           */
+    const double *fll_state_in;   /* [B][2] or NULL                                  */
+    double *fll_state_out;        /* [B][2] or NULL                                  */
+    void *rec, *err, *mu, *sig, *freq, *ef;   /* tiles [..][out_rows][64] or NULL    */
+    uint8_t *dec;
+    int64_t out_rows;
+    int32_t *n_out;         /* [B] or NULL                                           */
+    int32_t *status;        /* [B] or NULL; bit0 = capacity reached                  */
+} dsp_sync_args;
+
+/* Launches the fused recurrence kernel on the context stream (asynchronous).    */
+int dsp_sync_tiles_dev(dsp_ctx *ctx, const dsp_sync_args *args);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSP_HIP_H */

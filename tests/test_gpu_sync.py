@@ -1,0 +1,197 @@
+"""GPU parity tests of the Gardner / FLL recurrence kernels (call through the C ABI).
+
+Bars (north_star): hard QPSK decisions bit-exact; Gardner trajectories are
+float64 on the device with the reference's rounding, so they are compared for
+EXACT equality (float64 outputs) or exact equality after float32 rounding
+(complex64 path); FLL frequency within 1e-12 cycles/sample of the oracle (the
+north-star tolerance is 1e-4 rad/sample), derotated samples within 1e-9.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+FREQ_TOL = 1e-12
+SIG_TOL = 1e-9
+
+
+def _chain_oracle(O, y32, sps=4, alpha=0.007, Bn=0.03, scale=1.0):
+    return O.sync_chain_c64(y32, sps=sps, alpha=alpha, Bn=Bn, y=1.0, scale=scale)
+
+
+def test_dropin_gardner_config1_bit_exact(ctx):
+    import dsp_amd
+    g = golden("g_config1")
+    rec, err, mu = dsp_amd.gardner_timing_recovery(g["y"], 4, alpha=0.007)
+    assert rec.dtype == np.complex128 and mu.dtype == np.float64
+    assert len(rec) == 10499 and mu[-1] == -0.05891794872812668        # SURVEY 8c known answer
+    assert np.array_equal(rec, g["rec"])
+    assert np.array_equal(err, g["terr"])
+    assert np.array_equal(mu, g["mu"])
+    rec2, err2, mu2 = dsp_amd.gardner_timing_recovery(g["yd"], 4, alpha=0.04)
+    assert np.array_equal(rec2, g["rec2"]) and np.array_equal(mu2, g["mu2"])
+
+
+def test_dropin_fll_config1_stable_horizon(ctx):
+    """fll_func(rec, Bn=0.03): loop gain 2*pi*kp*i passes 2 at i ~ 3316, after which the
+    reference itself is chaotic (a 1e-12 input perturbation flips 40% of its decisions), so
+    parity is asserted on the first 3300 symbols (DESIGN.md 'FLL stability horizon')."""
+    import dsp_amd
+    g = golden("g_config1")
+    out, cf, freq, ef = dsp_amd.fll_func(g["rec"], 0.03, 1)
+    H = 3300
+    assert out.shape == g["fll_out"].shape
+    assert np.max(np.abs(freq[:H] - g["fll_freq"][:H])) < FREQ_TOL
+    assert np.max(np.abs(ef[:H] - g["fll_ef"][:H])) < FREQ_TOL
+    assert np.max(np.abs(out[:H] - g["fll_out"][:H])) < SIG_TOL
+    dec = (out.real < 0) + 2 * (out.imag < 0)
+    assert np.array_equal(dec[:H], g["dec"][:H])
+
+
+def test_dropin_fll_config2_full(ctx):
+    """diff_method.py:304-307: fll_func(y[0::4], 1e-6, 1) over all 10 471 symbols."""
+    import dsp_amd
+    g = golden("g_config2")
+    out, cf, freq, ef = dsp_amd.fll_func(g["y"][0::4], 0.000001, 1)
+    assert abs(cf - float(g["fllA_cf"])) < 1e-18
+    assert np.max(np.abs(freq - g["fllA_freq"])) < 1e-18
+    assert np.max(np.abs(out - g["fllA_out"])) < SIG_TOL
+    rec, err, mu = dsp_amd.gardner_timing_recovery(g["y"], 4, alpha=0.007)
+    assert len(rec) == 10470 and np.array_equal(rec, g["rec"]) and np.array_equal(mu, g["mu"])
+    out, cf, freq, ef = dsp_amd.fll_func(rec, 0.03, 1)
+    H = 3300
+    assert np.max(np.abs(freq[:H] - g["fllB_freq"][:H])) < FREQ_TOL
+    dec = (out.real < 0) + 2 * (out.imag < 0)
+    assert np.array_equal(dec[:H], g["dec"][:H])
+    assert list(dec[:16]) == [0, 3, 3, 1, 1, 3, 0, 1, 2, 3, 0, 2, 2, 1, 1, 3]
+
+
+def test_dropin_gardner_ted_hw1(ctx):
+    import dsp_amd
+    g = golden("g_hw1_gardner")
+    y, err, mu = dsp_amd.gardner_ted(g["baseband"], 2)
+    assert len(y) == 49998 and mu[-1] == 0.035570256412029266
+    assert np.array_equal(y, g["y"]) and np.array_equal(err, g["err"]) and np.array_equal(mu, g["mu"])
+    y2, err2, mu2 = dsp_amd.gardner_ted(g["baseband"][:12000], 2, delta_mu=0.005)
+    assert np.array_equal(y2, g["y2"]) and np.array_equal(mu2, g["mu2"])
+
+
+def test_dropin_gardner2_demo_sps8(ctx):
+    import dsp_amd
+    g = golden("g_gardner2_demo")
+    rec, err, mu = dsp_amd.gardner_timing_recovery(g["x"], 8, alpha=0.07, mu_initial=0.0)
+    assert np.array_equal(rec, g["rec"]) and np.array_equal(err, g["terr"]) and np.array_equal(mu, g["mu"])
+
+
+def test_edges(ctx):
+    import dsp_amd
+    g = golden("g_edges")
+    rng = np.random.default_rng(99)
+    z = rng.standard_normal(64) + 1j * rng.standard_normal(64)
+    for L in (1, 3, 4, 7, 8, 9, 12, 13):
+        rec, err, mu = dsp_amd.gardner_timing_recovery(z[:L], 4, alpha=0.05)
+        assert np.array_equal(rec, g[f"g2_len{L}_rec"]) and np.array_equal(mu, g[f"g2_len{L}_mu"])
+        y, e, m = dsp_amd.gardner_ted(z[:L], 4)
+        assert np.array_equal(y, g[f"ted_len{L}_y"]) and np.array_equal(m, g[f"ted_len{L}_mu"])
+    with pytest.raises(IndexError):
+        dsp_amd.gardner_timing_recovery(np.zeros(0, complex), 4)
+    # symbol slips in both directions (k += sps / k -= sps), mu_initial, clip at +-sps
+    for nm in ("pos", "mid", "negmid"):
+        rec, err, mu = dsp_amd.gardner_timing_recovery(g["wrap_x"], 4, alpha=float(g[f"g2_wrap_{nm}_alpha"]))
+        assert np.array_equal(rec, g[f"g2_wrap_{nm}_rec"]), nm
+        assert np.array_equal(err, g[f"g2_wrap_{nm}_err"]) and np.array_equal(mu, g[f"g2_wrap_{nm}_mu"])
+    rec, err, mu = dsp_amd.gardner_timing_recovery(g["wrap_x"], 4, alpha=0.007, mu_initial=3.7)
+    assert np.array_equal(rec, g["g2_mu0_rec"]) and np.array_equal(mu, g["g2_mu0_mu"])
+    y, e, m = dsp_amd.gardner_ted(g["wrap_x"], 4, delta_mu=0.8)
+    assert np.array_equal(y, g["ted_clip_y"]) and np.array_equal(e, g["ted_clip_err"])
+    assert np.array_equal(m, g["ted_clip_mu"])
+    # fll: exact zeros and pure-axis samples (np.sign(0) = 0), other loop constants, empty
+    out, cf, freq, ef = dsp_amd.fll_func(g["fll_axis_x"], 50.0, 1)
+    assert np.max(np.abs(freq - g["fll_axis_freq"])) < 1e-15
+    assert np.max(np.abs(out - g["fll_axis_out"])) < 1e-12
+    out, cf, freq, ef = dsp_amd.fll_func(g["wrap_x"][::4], 0.5, 0.707)
+    assert np.max(np.abs(freq - g["fll_y707_freq"])) < FREQ_TOL
+    out, cf, freq, ef = dsp_amd.fll_func(np.zeros(0, complex), 0.03, 1)
+    assert cf == 0 and out.size == 0
+
+
+def test_chain_c64_golden_bursts(ctx, oracle):
+    """Fused Gardner->FLL->decisions on complex64 matched-filtered bursts vs the reference
+    (golden chain B) for the 6 fully stored bursts, vs the oracle for all 32."""
+    import dsp_amd
+    g = golden("g_synth_bursts")
+    h = dsp_amd.rrc_filter(4, 10, 0.35)
+    X = g["x"]
+    Y32 = np.stack([oracle.filter_samples(X[b], h).astype(np.complex64) for b in range(X.shape[0])])
+    r = dsp_amd.sync_chain_batch(Y32, 4, 0.007, 0.0, 0.03, 1)
+    assert np.array_equal(r["n_out"], g["n_recB"])
+    assert np.array_equal(r["dec"][:, :2048], g["decB"])                     # all 32 bursts, bit-exact
+    for b in range(6):
+        n = int(g["n_recB"][b])
+        assert np.array_equal(r["rec"][b, :n], g["recB"][b, :n].astype(np.complex64))
+        assert np.array_equal(r["mu"][b, :n - 1], g["muB"][b, :n - 1].astype(np.float32))
+        assert np.array_equal(r["err"][b, :n - 1], g["terrB"][b, :n - 1].astype(np.float32))
+        assert np.max(np.abs(r["freq"][b, :n] - g["fllB_freq"][b, :n])) < 1e-9    # float32 output
+        assert np.max(np.abs(r["sig"][b, :n] - g["fllB_out"][b, :n])) < 1e-6
+    for b in range(X.shape[0]):
+        o = _chain_oracle(oracle, Y32[b])
+        n = o["n"]
+        assert np.array_equal(r["dec"][b, :n], o["dec"])
+        assert np.array_equal(r["mu"][b, :n - 1], o["mu"].astype(np.float32))
+        assert np.array_equal(r["freq"][b, :n], o["freq"].astype(np.float32)) or \
+            np.max(np.abs(r["freq"][b, :n] - o["freq"])) < 1e-9
+    # float64 path on the same bursts (complex128 in -> float64 out): tight FLL tolerance
+    Y = np.stack([oracle.filter_samples(X[b], h) for b in range(8)])
+    r64 = dsp_amd.sync_chain_batch(Y, 4, 0.007, 0.0, 0.03, 1)
+    for b in range(6):
+        n = int(g["n_rec"][b])
+        assert r64["n_out"][b] == n
+        assert np.max(np.abs(r64["rec"][b, :n] - g["rec"][b, :n])) < 1e-12   # y differs from golden y by FIR order
+        assert np.max(np.abs(r64["freq"][b, :n] - g["fll_freq"][b, :n])) < 1e-12
+        assert np.array_equal(r64["dec"][b, :n], g["dec"][b, :n])
+
+
+def test_chain_ragged_and_scale(ctx, oracle):
+    """Ragged burst lengths (incl. 0 and < 2*sps), partial tile (B not a multiple of 64),
+    per-burst input scale."""
+    import dsp_amd
+    rng = np.random.default_rng(5)
+    B, N = 70, 1536
+    h = dsp_amd.rrc_filter(4, 10, 0.35)
+    from dsp_amd.synth import synth_burst
+    X = np.stack([oracle.filter_samples(synth_burst(500 + b, h, n_sym=N // 4), h).astype(np.complex64)
+                  for b in range(B)])
+    lens = rng.integers(0, N + 1, B).astype(np.int32)
+    lens[:6] = [0, 1, 7, 8, 9, N]
+    scale = rng.uniform(0.5, 2.0, B)
+    r = dsp_amd.sync_chain_batch(X, 4, 0.01, 0.0, 0.03, 1, lens=lens, scale=scale)
+    for b in range(B):
+        L = int(lens[b])
+        if L == 0:
+            assert r["n_out"][b] == 0
+            continue
+        o = oracle.sync_chain_c64(X[b, :L], sps=4, alpha=0.01, Bn=0.03, y=1.0, scale=float(scale[b]))
+        n = o["n"]
+        assert r["n_out"][b] == n, (b, L)
+        assert np.array_equal(r["dec"][b, :n], o["dec"]), b
+        assert np.array_equal(r["rec"][b, :n], o["rec"].astype(np.complex64)), b
+        assert np.array_equal(r["mu"][b, :n - 1], o["mu"].astype(np.float32)), b
+        assert np.all(r["dec"][b, n:] == 0) and np.all(r["rec"][b, n:] == 0)
+
+
+def test_fll_batch_state_continuation(ctx, oracle):
+    """fll_batch with i0/state continues a loop exactly where a first call stopped."""
+    import dsp_amd
+    g = golden("g_synth_bursts")
+    rec = g["recB"][:4, :2048]
+    full = dsp_amd.fll_batch(rec, 0.03, 1)
+    a = dsp_amd.fll_batch(rec[:, :1000], 0.03, 1, want_state=True)
+    b = dsp_amd.fll_batch(rec[:, 1000:], 0.03, 1, i0=1000, state=a[5], want_state=True)
+    assert np.array_equal(np.concatenate([a[2], b[2]], axis=1), full[2])
+    assert np.array_equal(np.concatenate([a[4], b[4]], axis=1), full[4])
+    for i in range(4):
+        o = oracle.fll_func(rec[i], 0.03, 1)
+        assert np.max(np.abs(full[2][i] - o[2])) < FREQ_TOL
+        assert np.array_equal(full[4][i], oracle.quadrants(o[0]))
