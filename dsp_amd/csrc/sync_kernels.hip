@@ -76,6 +76,20 @@ __device__ __forceinline__ void wait_vmcnt(int n)
     }
 }
 
+// transcendental constants: loaded once per lane through an opaque index so that they
+// stay in VGPRs (see dsp_math.h)
+__device__ const double k_math_table[dspm::K_COUNT] = DSP_MATH_TABLE_INIT;
+
+__device__ __forceinline__ dspm::MathK load_math_consts()
+{
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    dspm::MathK k;
+#pragma unroll
+    for (int i = 0; i < dspm::K_COUNT; i++) k.v[i] = k_math_table[z + i];
+    return k;
+}
+
 template <typename IN> struct InT;
 template <> struct InT<f2v> { typedef float S; typedef float OS; typedef f2v OC; enum { RPP = 2 }; };
 template <> struct InT<d2v> { typedef double S; typedef double OS; typedef d2v OC; enum { RPP = 1 }; };
@@ -156,6 +170,8 @@ __global__ __launch_bounds__(64) void sync_kernel(SyncParams P)
         if (P.i0) i0 = P.i0[b];
     }
     const double kp = P.kp, ki = P.ki, alpha = P.alpha;
+    dspm::MathK MK;
+    if (FLL) MK = load_math_consts();
 
     OC *o_rec = (OC *)P.rec; OS *o_terr = (OS *)P.terr; OS *o_mu = (OS *)P.mu;
     OC *o_sig = (OC *)P.sig; OS *o_freq = (OS *)P.freq; OS *o_ef = (OS *)P.ef;
@@ -173,6 +189,17 @@ __global__ __launch_bounds__(64) void sync_kernel(SyncParams P)
     if (VARIANT == DSP_VARIANT_NONE) gs.active = false;
     bool overflow = false;
 
+    // straight-line LDS access for the fast path (row known to be inside the ring window)
+    auto lds_at = [&](int row) -> cd {
+        IN v = ((const IN *)smem)[(row & RM) * 64 + lane];
+        cd z;
+        z.re = (double)v.x * scale;
+        z.im = (double)v.y * scale;
+        return z;
+    };
+    const double spsd = (double)sps, lend = (double)len;
+    const double halfd = (VARIANT == DSP_VARIANT_TED) ? spsd / 2.0 : (double)(sps / 2);
+
     int it = 0;
     bool running = true;
     for (int blk = 0; running; blk++) {
@@ -189,31 +216,119 @@ __global__ __launch_bounds__(64) void sync_kernel(SyncParams P)
             const int fll_row = it - ROFF;
             if (fll_row >= out_rows) { running = false; break; }      // capacity (uniform)
 
-            // ---- FLL on the symbol appended by the previous iteration ------
-            dspm::FllOut fo; fo.sr = 0.0; fo.si = 0.0; fo.ef = 0.0; fo.freq = 0.0; fo.quad = 0;
+            // ---- FLL on the symbol appended by the previous iteration: computed by every
+            //      lane, committed by select (no divergent control flow) ----------------
+            double f_sr = 0.0, f_si = 0.0, f_ef = 0.0, f_freq = 0.0;
+            unsigned f_quad = 0;
             if (FLL) {
-                if (pending) fo = dspm::fll_step(rec_prev.re, rec_prev.im, (double)fll_row + i0,
-                                                 freq, integ, kp, ki);
+                double nf = freq, ni = integ;
+                dspm::FllOut fo = dspm::fll_step(MK, rec_prev.re, rec_prev.im, (double)fll_row + i0,
+                                                 nf, ni, kp, ki);
+                freq = pending ? nf : freq;
+                integ = pending ? ni : integ;
+                f_sr = pending ? fo.sr : 0.0; f_si = pending ? fo.si : 0.0;
+                f_ef = pending ? fo.ef : 0.0; f_freq = pending ? fo.freq : 0.0;
+                f_quad = pending ? (unsigned)fo.quad : 0u;
             }
+
             // ---- timing loop: one pass of the reference's loop body --------
             dspm::GOut go; go.produced = false; go.rec.re = 0.0; go.rec.im = 0.0; go.err = 0.0; go.mu = 0.0;
             if (VARIANT == DSP_VARIANT_NONE) {
-                if (pending && it + 1 < len) { go.rec = fetch(it + 1); go.produced = true; }
+                const bool have = pending && (it + 1 < len);
+                if (it + 1 >= win_lo && it + 1 < win_hi) {            // uniform
+                    cd v = lds_at(it + 1);
+                    go.rec.re = have ? v.re : 0.0; go.rec.im = have ? v.im : 0.0;
+                } else if (have) {
+                    go.rec = fetch(it + 1);
+                }
+                go.produced = have;
             } else {
                 if (gs.active && rec_row >= out_rows) { gs.active = false; overflow = true; }
-                if (VARIANT == DSP_VARIANT_GARDNER2)
-                    go = dspm::gardner2_iter(gs, len, sps, alpha, Lp, fetch);
-                else
-                    go = dspm::ted_iter(gs, len, sps, n_symbols, alpha, Lp, fetch);
+                bool fast = !LAGR;
+                bool ok = false;
+                double mu = gs.mu, i_a = 0.0, i_b = 0.0, i_c = 0.0;
+                int r_a = 0, r_b = 0, r_c = 0;
+                if (!LAGR) {
+                    if (VARIANT == DSP_VARIANT_GARDNER2) {
+                        // gardner2.py:63-80 without the wrap loops (a lane that needs them, or
+                        // rows outside the ring, sends the wave down the generic path)
+                        const bool cont = gs.active && (gs.k <= len - sps);
+                        const double kd = (double)gs.k;
+                        const bool odd = cont && !(mu < spsd && mu >= -spsd);   // wrap or NaN
+                        i_a = (kd - spsd) + mu;           // idx_early
+                        i_b = (kd - halfd) + mu;          // idx_mid
+                        i_c = kd + mu;                    // idx_late
+                        ok = cont && !(i_a < 0.0) && !(i_c + 1.0 >= lend);
+                        r_a = __double2int_rz(i_a); r_b = __double2int_rz(i_b); r_c = __double2int_rz(i_c);
+                        const bool inwin = (r_a >= win_lo) && (r_c + 1 < win_hi);
+                        fast = !__any(odd || (ok && !inwin));
+                    } else {
+                        // hw1/gardner.py:45-53
+                        const bool cont = gs.active && (gs.k < n_symbols);
+                        const double base = (double)(gs.k * sps);
+                        i_a = base + mu;                                   // idx_k
+                        i_c = (double)((gs.k + 1) * sps) + mu;             // idx_next
+                        i_b = base + mu + halfd;                           // idx_mid
+                        ok = cont && !(i_c + 1.0 >= lend || i_b + 1.0 >= lend);
+                        const double fa = dspm::d_floor(i_a), fb = dspm::d_floor(i_b), fc = dspm::d_floor(i_c);
+                        r_a = __double2int_rz(fa); r_b = __double2int_rz(fb); r_c = __double2int_rz(fc);
+                        const bool inwin = (r_a >= win_lo) && (r_c + 1 < win_hi) && (r_a >= 0);
+                        fast = !__any(ok && !inwin);
+                    }
+                }
+                if (fast) {
+                    cd a0 = lds_at(r_a), a1 = lds_at(r_a + 1);
+                    cd b0 = lds_at(r_b), b1 = lds_at(r_b + 1);
+                    cd c0 = lds_at(r_c), c1 = lds_at(r_c + 1);
+                    cd xa = dspm::lerp(a0, a1, i_a - (double)r_a);
+                    cd xb = dspm::lerp(b0, b1, i_b - (double)r_b);
+                    cd xc = dspm::lerp(c0, c1, i_c - (double)r_c);
+                    const double e = dspm::ted_error(xa, xb, xc);
+                    cd rec; rec.re = 0.0; rec.im = 0.0;
+                    double mu_n, mu_hist;
+                    if (VARIANT == DSP_VARIANT_GARDNER2) {
+                        mu_n = mu - alpha * e;                              // :91
+                        mu_hist = mu_n;
+                        const double i_o = (double)gs.k + mu_n;             // :95
+                        const int r_o = __double2int_rz(i_o);
+                        const int hi_lim = win_hi < len ? win_hi : len;
+                        const bool ofast = (i_o > -1.0e9 && i_o < 1.0e9) && r_o >= win_lo && r_o + 1 < hi_lim;
+                        if (!__any(ok && !ofast)) {
+                            rec = dspm::lerp(lds_at(r_o), lds_at(r_o + 1), i_o - (double)r_o);
+                        } else if (ok) {
+                            rec = dspm::g2_interp(i_o, len, (const dspm::LagrangeW *)nullptr, fetch);
+                        }
+                        if (ok) gs.k += sps;                                // :98
+                    } else {
+                        mu_hist = mu;                                       // :63
+                        rec = xa;                                           // :72
+                        mu_n = mu + alpha * e;                              // :66
+                        mu_n = mu_n < -spsd ? -spsd : mu_n;                 // :69
+                        mu_n = mu_n > spsd ? spsd : mu_n;
+                        if (ok) gs.k += 1;
+                    }
+                    gs.mu = ok ? mu_n : mu;
+                    gs.active = ok;
+                    go.produced = ok;
+                    go.err = ok ? e : 0.0;
+                    go.mu = ok ? mu_hist : 0.0;
+                    go.rec.re = ok ? rec.re : 0.0;
+                    go.rec.im = ok ? rec.im : 0.0;
+                } else {
+                    if (VARIANT == DSP_VARIANT_GARDNER2)
+                        go = dspm::gardner2_iter(gs, len, sps, alpha, Lp, fetch);
+                    else
+                        go = dspm::ted_iter(gs, len, sps, n_symbols, alpha, Lp, fetch);
+                }
             }
             // ---- stores: unconditional, one instruction per enabled output -
             const int frow = fll_row < 0 ? 0 : fll_row;
             const size_t fo_off = obase + (size_t)frow * 64;
             if (FLL) {
-                if (o_sig) st_cplx(o_sig + fo_off, fo.sr, fo.si);
-                if (o_freq) st_val(o_freq + fo_off, fo.freq);
-                if (o_ef) st_val(o_ef + fo_off, fo.ef);
-                if (o_dec) st_b8(o_dec + fo_off, (unsigned)fo.quad);
+                if (o_sig) st_cplx(o_sig + fo_off, f_sr, f_si);
+                if (o_freq) st_val(o_freq + fo_off, f_freq);
+                if (o_ef) st_val(o_ef + fo_off, f_ef);
+                if (o_dec) st_b8(o_dec + fo_off, f_quad);
             }
             if (VARIANT != DSP_VARIANT_NONE) {
                 const int rrow = rec_row < out_rows ? rec_row : out_rows - 1;
@@ -224,7 +339,7 @@ __global__ __launch_bounds__(64) void sync_kernel(SyncParams P)
             }
             pending = go.produced;
             rec_prev = go.rec;
-            if (go.produced) n_rec++;
+            n_rec += go.produced ? 1 : 0;
         }
     }
     if (lane_ok) {

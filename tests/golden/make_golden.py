@@ -156,8 +156,16 @@ bb = iq * np.exp(-1j * 2 * np.pi * (-0.00026) * n)
 yt, et, mt = ref_hw1g.gardner_ted(bb, 2)
 assert np.array_equal(yt, ref_hw1g.y_file)
 yt2, et2, mt2 = ref_rf.gardner_ted(bb[:12000], 2, delta_mu=0.005)
+# NOTE (numpy >= 2, NEP 50): bb is complex64 and gardner_ted's Python-float constants are
+# "weak", so the run above silently computes in float32 (mu, the sample index and the
+# interpolation all become float32 after the first iteration).  The same function on the
+# complex128 view of the same samples is the float64 algorithm every other call site runs.
+bb128 = bb.astype(np.complex128)
+yd_, ed_, md_ = ref_hw1g.gardner_ted(bb128, 2)
+yd2_, ed2_, md2_ = ref_rf.gardner_ted(bb128[:12000], 2, delta_mu=0.005)
 save("g_hw1_gardner", datafile=np.array(f3), iq=iq, iq_raw=iq_raw, baseband=bb,
-     y=yt, err=et, mu=mt, y2=yt2, err2=et2, mu2=mt2)
+     y=yt, err=et, mu=mt, y2=yt2, err2=et2, mu2=mt2,
+     y_f64=yd_, err_f64=ed_, mu_f64=md_, y2_f64=yd2_, err2_f64=ed2_, mu2_f64=md2_)
 
 # ---------------------------------------------------------------------------
 # G4: gardner2.py __main__ demo (:102-138): seed 1, sps 8, delay .095, alpha .07

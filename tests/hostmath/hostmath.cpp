@@ -6,16 +6,18 @@
 
 using namespace dspm;
 
+static const MathK KK = math_consts_literal();
+
 extern "C" {
 
 void hm_sincos(const double *x, int64_t n, double *s, double *c)
 {
-    for (int64_t i = 0; i < n; i++) sincos_f64(x[i], s[i], c[i]);
+    for (int64_t i = 0; i < n; i++) sincos_f64(KK, x[i], s[i], c[i]);
 }
 
 void hm_atan2(const double *y, const double *x, int64_t n, double *out)
 {
-    for (int64_t i = 0; i < n; i++) out[i] = atan2_f64(y[i], x[i]);
+    for (int64_t i = 0; i < n; i++) out[i] = atan2_f64(KK, y[i], x[i]);
 }
 
 // fll_func over a complex128 array with the device step function
@@ -24,7 +26,7 @@ double hm_fll(const double *x, int64_t M, double kp, double ki, int64_t i0, doub
 {
     double f = state ? state[0] : 0.0, integ = state ? state[1] : 0.0;
     for (int64_t i = 0; i < M; i++) {
-        FllOut o = fll_step(x[2 * i], x[2 * i + 1], (double)(i + i0), f, integ, kp, ki);
+        FllOut o = fll_step(KK, x[2 * i], x[2 * i + 1], (double)(i + i0), f, integ, kp, ki);
         out[2 * i] = o.sr; out[2 * i + 1] = o.si; freq[i] = o.freq; ef[i] = o.ef;
         quad[i] = (uint8_t)o.quad;
     }

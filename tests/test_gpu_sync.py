@@ -69,13 +69,21 @@ def test_dropin_fll_config2_full(ctx):
 
 
 def test_dropin_gardner_ted_hw1(ctx):
+    """hw1/gardner.py:94-117 flow.  The float64 algorithm (reference run on the complex128 view of
+    the samples) is matched bit for bit.  The reference's own script passes a complex64 array, and
+    under numpy >= 2 (NEP 50) that makes its Python-float constants weak: the loop silently runs in
+    float32 (mu, sample index, interpolation).  Against that run the float64 device result agrees
+    within the north-star timing tolerance (1e-3 symbol)."""
     import dsp_amd
     g = golden("g_hw1_gardner")
     y, err, mu = dsp_amd.gardner_ted(g["baseband"], 2)
-    assert len(y) == 49998 and mu[-1] == 0.035570256412029266
-    assert np.array_equal(y, g["y"]) and np.array_equal(err, g["err"]) and np.array_equal(mu, g["mu"])
+    assert len(y) == 49998
+    assert np.array_equal(y, g["y_f64"]) and np.array_equal(err, g["err_f64"])
+    assert np.array_equal(mu, g["mu_f64"])
+    assert np.max(np.abs(mu - g["mu"])) / 2 < 1e-3           # float32-accident run, in symbols
+    assert abs(mu[-1] - 0.035570256412029266) / 2 < 1e-3     # SURVEY 8c known answer (float32 run)
     y2, err2, mu2 = dsp_amd.gardner_ted(g["baseband"][:12000], 2, delta_mu=0.005)
-    assert np.array_equal(y2, g["y2"]) and np.array_equal(mu2, g["mu2"])
+    assert np.array_equal(y2, g["y2_f64"]) and np.array_equal(mu2, g["mu2_f64"])
 
 
 def test_dropin_gardner2_demo_sps8(ctx):
@@ -111,8 +119,10 @@ def test_edges(ctx):
     out, cf, freq, ef = dsp_amd.fll_func(g["fll_axis_x"], 50.0, 1)
     assert np.max(np.abs(freq - g["fll_axis_freq"])) < 1e-15
     assert np.max(np.abs(out - g["fll_axis_out"])) < 1e-12
+    # Bn 0.5, y 0.707: kp = 1.886e-3, loop gain 2*pi*kp*i passes 2 at i = 169 -> compare 150 symbols
     out, cf, freq, ef = dsp_amd.fll_func(g["wrap_x"][::4], 0.5, 0.707)
-    assert np.max(np.abs(freq - g["fll_y707_freq"])) < FREQ_TOL
+    assert np.max(np.abs(freq[:150] - g["fll_y707_freq"][:150])) < FREQ_TOL
+    assert np.max(np.abs(out[:150] - g["fll_y707_out"][:150])) < SIG_TOL
     out, cf, freq, ef = dsp_amd.fll_func(np.zeros(0, complex), 0.03, 1)
     assert cf == 0 and out.size == 0
 
