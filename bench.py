@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--ring-rows", type=int, default=0)
     ap.add_argument("--lds-pad", type=int, default=-1)
+    ap.add_argument("--split", type=int, default=-1, help="-1 auto, 0 one wave per tile, 1 two")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -107,6 +108,7 @@ def main():
         ctx.set_option("ring_rows", args.ring_rows)
     if args.lds_pad >= 0:
         ctx.set_option("lds_pad", args.lds_pad)
+    ctx.set_option("split", args.split)
     L = lib()
     B = args.bursts
     ntiles = (B + 63) // 64

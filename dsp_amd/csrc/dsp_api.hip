@@ -17,6 +17,7 @@ struct dsp_ctx {
     hipEvent_t ev0, ev1;
     int ring_rows;      // 0 = automatic
     int lds_pad;        // extra dynamic LDS per workgroup (bytes) to steer workgroups per CU
+    int split;          // -1 auto / 1: two waves per tile where applicable; 0: one wave per tile
 };
 
 static thread_local char g_err[512] = "";
@@ -72,6 +73,7 @@ int dsp_create(int device_id, dsp_ctx **out)
     c->own_stream = true;
     c->ring_rows = 0;
     c->lds_pad = -1;
+    c->split = -1;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
@@ -120,6 +122,8 @@ int dsp_set_option(dsp_ctx *c, const char *name, int64_t value)
         c->ring_rows = (int)value;
     } else if (!strcmp(name, "lds_pad")) {
         c->lds_pad = (int)value;
+    } else if (!strcmp(name, "split")) {
+        c->split = (int)value;
     } else {
         return fail(DSP_E_ARG, "unknown option '%s'", name);
     }
@@ -272,7 +276,7 @@ int dsp_sync_tiles_dev(dsp_ctx *c, const dsp_sync_args *a)
     if (a->N < 0 || a->N >= (1LL << 30)) return fail(DSP_E_ARG, "sync: N out of range");
     if (a->in_rows < a->N || a->in_rows < 2 || (a->in_rows & 1))
         return fail(DSP_E_ARG, "sync: in_rows must be even and >= N (use dsp_tile_rows)");
-    if (a->out_rows < 1 || a->out_rows >= (1LL << 30)) return fail(DSP_E_ARG, "sync: bad out_rows");
+    if (a->out_rows < 2 || a->out_rows >= (1LL << 30)) return fail(DSP_E_ARG, "sync: bad out_rows");
     if (a->interp_half_len < 0 || a->interp_half_len > 8)
         return fail(DSP_E_ARG, "sync: interp_half_len must be in [0,8]");
     if (fll && !(a->y > 0.0)) return fail(DSP_E_ARG, "sync: y must be > 0");
@@ -291,27 +295,43 @@ int dsp_sync_tiles_dev(dsp_ctx *c, const dsp_sync_args *a)
     P.dec = fll ? a->dec : nullptr;
     P.out_rows = (int)a->out_rows; P.n_out = a->n_out; P.status = a->status;
 
-    int n_store = count_nonnull({P.rec, P.terr, P.mu, P.sig, P.freq, P.ef, P.dec});
-    int elem = a->dtype == DSP_C128 ? 16 : 8;
+    // ---- kernel shape -------------------------------------------------------
+    // One workgroup per tile; its dynamic LDS (input ring [+ hand-off queue]) also sets how
+    // many tiles a CU holds (160 KiB per CU), so size it for an even spread over 256 CUs.
+    const int elem = a->dtype == DSP_C128 ? 16 : 8;
+    const int ntiles = (P.B + 63) / 64;
+    const bool can_split = fll && a->variant != 2 && P.half_len == 0;
+    const bool split = can_split && c->split != 0;
+    const int n_store_t = count_nonnull({P.rec, P.terr, P.mu});
+    const int n_store_f = count_nonnull({P.sig, P.freq, P.ef, P.dec});
+    const int n_store = split ? n_store_t : n_store_t + n_store_f;
+    int per_cu = (ntiles + 255) / 256;
+    if (per_cu < 1) per_cu = 1;
+    size_t budget = ((size_t)160 * 1024 / per_cu) & ~(size_t)511;
+    if (budget > 64 * 1024) budget = 64 * 1024;
     int R = c->ring_rows;
-    if (R == 0) R = (sps > 8 || P.half_len > 2) ? 128 : 64;
-    if (R * 64 * elem > 64 * 1024) R = 64 * 1024 / (64 * elem);
+    if (R == 0) {
+        R = (sps > 8 || P.half_len > 2) ? 128 : 64;
+        // prefer a smaller ring when that lets every tile be resident at once
+        while (R > 32 && (size_t)R * 64 * elem + (split ? 2200 : 0) > budget &&
+               sync_plan(elem, sps, P.half_len, a->variant, n_store, R / 2).use_ring)
+            R /= 2;
+    }
+    if ((size_t)R * 64 * elem > 64 * 1024) R = 64 * 1024 / (64 * elem);
     SyncPlan pl = sync_plan(elem, sps, P.half_len, a->variant, n_store, R);
     P.use_ring = pl.use_ring; P.ring_rows = pl.ring_rows; P.T = pl.T; P.C = pl.C; P.nwait = pl.nwait;
-
-    // Dynamic LDS also steers residency: one wave per workgroup, so workgroups per
-    // CU = floor(160 KiB / lds).  By default spread the tiles evenly over 256 CUs.
     size_t lds = (size_t)pl.lds_bytes;
-    int ntiles = (P.B + 63) / 64;
-    if (c->lds_pad >= 0) {
-        lds += (size_t)c->lds_pad;
-    } else {
-        int per_cu = (ntiles + 255) / 256;
-        if (per_cu < 1) per_cu = 1;
-        size_t even = ((size_t)160 * 1024 / per_cu) & ~(size_t)1023;
-        if (even > 64 * 1024) even = 64 * 1024;
-        if (even > lds) lds = even;
+    P.TQ = 0;
+    if (split) {
+        // queue block: the largest divisor of T whose double buffer still fits the budget
+        int TQ = 1;
+        for (int d = pl.T; d >= 1; d--)
+            if (pl.T % d == 0 && lds + (size_t)2 * d * 64 * 17 + 16 <= budget) { TQ = d; break; }
+        P.TQ = TQ;
+        lds += (size_t)2 * TQ * 64 * 17 + 16;
     }
+    if (c->lds_pad >= 0) lds += (size_t)c->lds_pad;
+    else if (budget > lds) lds = budget;
     if (lds > 64 * 1024) lds = 64 * 1024;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(launch_sync(P, a->dtype == DSP_C128, a->variant, fll, lds, c->stream));
@@ -361,7 +381,7 @@ static int run_host(dsp_ctx *c, const void *x, int dtype, int64_t B, int64_t N, 
     const int ce = dtype == DSP_C128 ? 16 : 8, re = ce / 2;
     const int64_t rows = dsp_tile_rows(N);
     const int64_t ntiles = (B + 63) / 64;
-    const int64_t out_rows = out_stride;
+    const int64_t out_rows = out_stride + 1;      // + the kernels' scratch row
     hipStream_t s = c->stream;
 
     DevBuf d_x, d_xt, d_lens, d_scale, d_i0, d_stin, d_stout, d_nout, d_status, d_stage;
@@ -418,7 +438,7 @@ static int run_host(dsp_ctx *c, const void *x, int dtype, int64_t B, int64_t N, 
     for (auto &o : outs) {
         if (!o.host) continue;
         HIP_TRY(launch_bursts_from_tiles(o.tiles.p, (int)out_rows, (int)B, d_stage.p, out_stride,
-                                         (int)out_rows, o.elem, s));
+                                         (int)out_stride, o.elem, s));
         HIP_TRY(hipMemcpyAsync(o.host, d_stage.p, (size_t)B * out_stride * o.elem,
                                hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));

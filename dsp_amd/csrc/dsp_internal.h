@@ -40,6 +40,7 @@ struct SyncParams {
     int *status;              // [B] bit0: output capacity reached before the loop ended
     // LDS ring schedule (host-computed, see sync_plan())
     int use_ring, ring_rows, T, C, nwait;
+    int TQ;                   // > 0: split kernel, queue block length (iterations); T % TQ == 0
 };
 
 struct SyncPlan { int use_ring, ring_rows, T, C, nwait, lds_bytes; };

@@ -95,35 +95,23 @@ template <> struct InT<f2v> { typedef float S; typedef float OS; typedef f2v OC;
 template <> struct InT<d2v> { typedef double S; typedef double OS; typedef d2v OC; enum { RPP = 1 }; };
 
 // ---------------------------------------------------------------------------
-template <typename IN, int VARIANT, bool FLL, bool LAGR>
-__global__ __launch_bounds__(64) void sync_kernel(SyncParams P)
-{
-    typedef typename InT<IN>::OS OS;     // output scalar (float for c64 in, double for c128 in)
-    typedef typename InT<IN>::OC OC;     // output complex
-    constexpr int RPP = InT<IN>::RPP;    // rows per 1 KiB DMA piece
+// One wave's view of its tile: the input stream, the LDS ring and its window.
+template <typename IN>
+struct Tile {
+    const IN *xt;                 // this tile's rows in global memory
+    const unsigned char *ring;    // LDS ring base (generic pointer)
+    unsigned lds_base;            // LDS byte address of the ring
+    int lane, RM, R, in_rows;
+    int win_lo, win_hi;           // rows [win_lo, win_hi) are valid in the ring
+    int F;                        // DMA front: rows [0, F) have been issued
+    double scale;
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x;
-    const int tile = blockIdx.x;
-    const int b = tile * 64 + lane;
-    const bool lane_ok = b < P.B;
-    const int len = lane_ok ? (P.lens ? P.lens[b] : P.len_all) : 0;
-    const double scale = (lane_ok && P.scale) ? P.scale[b] : 1.0;
-    const int in_rows = P.in_rows, out_rows = P.out_rows, sps = P.sps;
-    const IN *xt = (const IN *)P.x + (size_t)tile * in_rows * 64;
-    const size_t obase = (size_t)tile * out_rows * 64 + lane;
-
-    const int R = P.ring_rows, RM = R - 1, T = P.T;
-    const bool ring = P.use_ring != 0;
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
-
-    int win_lo = 0, win_hi = 0;          // rows [win_lo, win_hi) are valid in the ring
-    int F = 0;                           // DMA front: rows [0, F) have been issued
-
-    auto fetch = [&](int row) -> cd {
+    // generic access: ring if the row is inside the window, else global memory
+    __device__ __forceinline__ cd fetch(int row) const
+    {
         IN v;
         if ((unsigned)(row - win_lo) < (unsigned)(win_hi - win_lo)) {
-            v = ((const IN *)smem)[(row & RM) * 64 + lane];
+            v = ((const IN *)ring)[(row & RM) * 64 + lane];
         } else {
             int r = row < 0 ? 0 : (row >= in_rows ? in_rows - 1 : row);
             v = xt[(size_t)r * 64 + lane];
@@ -133,43 +121,223 @@ __global__ __launch_bounds__(64) void sync_kernel(SyncParams P)
         z.re = (double)v.x * scale;
         z.im = (double)v.y * scale;
         return z;
-    };
-    auto issue = [&](int F_new) {
+    }
+    // straight-line access, row known to be inside the window
+    __device__ __forceinline__ cd lds_at(int row) const
+    {
+        IN v = ((const IN *)ring)[(row & RM) * 64 + lane];
+        cd z;
+        z.re = (double)v.x * scale;
+        z.im = (double)v.y * scale;
+        return z;
+    }
+    // issue the DMA pieces for rows [F, F_new)
+    __device__ __forceinline__ void issue(int F_new)
+    {
+        constexpr int RPP = InT<IN>::RPP;
         F_new = F_new < in_rows ? F_new : in_rows;
         for (int r = F; r < F_new; r += RPP) {
             const unsigned char *g = (const unsigned char *)(xt + (size_t)r * 64) + lane * 16;
             lds_dma_16B(g, lds_base + (unsigned)((r & RM) * 64 * (int)sizeof(IN)));
         }
         F = F_new > F ? F_new : F;
-    };
-
-    if (ring) {                          // prologue: rows for block 0
-        issue(sps * T + P.C);
+    }
+    // start of DMA block `blk` (T iterations of `step` rows each)
+    __device__ __forceinline__ void advance(int blk, int step, int T, int C, int nwait)
+    {
+        if (blk > 0) wait_vmcnt(nwait);     // the previous block's DMA has landed
+        win_hi = F;
+        issue(step * (blk + 2) * T + C);
+        win_lo = F - R > 0 ? F - R : 0;
+    }
+    __device__ __forceinline__ void prologue(int step, int T, int C)
+    {
+        issue(step * T + C);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         win_hi = F;
     }
+};
+
+template <typename IN>
+struct FetchFn {
+    const Tile<IN> &t;
+    __device__ __forceinline__ cd operator()(int row) const { return t.fetch(row); }
+};
+
+struct TimingConst {
+    int len, sps, n_symbols;
+    double spsd, lend, halfd, alpha;
+};
+
+// One pass of the timing loop body for every lane of the wave.  Fast path: no
+// lane needs the wrap loops and all rows are inside the ring window -> straight
+// line code, results committed by select.  Otherwise the generic per-lane code.
+template <typename IN, int VARIANT, bool LAGR>
+__device__ __forceinline__ dspm::GOut timing_iter(const Tile<IN> &tl, dspm::GState &gs, const TimingConst &tc,
+                                                  const dspm::LagrangeW *Lp)
+{
+    dspm::GOut go; go.produced = false; go.rec.re = 0.0; go.rec.im = 0.0; go.err = 0.0; go.mu = 0.0;
+    const int len = tc.len, sps = tc.sps;
+    const double spsd = tc.spsd, lend = tc.lend, alpha = tc.alpha;
+    const int win_lo = tl.win_lo, win_hi = tl.win_hi;
+    bool fast = !LAGR;
+    bool ok = false;
+    double mu = gs.mu, i_a = 0.0, i_b = 0.0, i_c = 0.0;
+    int r_a = 0, r_b = 0, r_c = 0;
+    if (!LAGR) {
+        if (VARIANT == DSP_VARIANT_GARDNER2) {
+            // gardner2.py:63-80 without the wrap loops
+            const bool cont = gs.active && (gs.k <= len - sps);
+            const double kd = (double)gs.k;
+            const bool odd = cont && !(mu < spsd && mu >= -spsd);   // wrap needed, or NaN
+            i_a = (kd - spsd) + mu;           // idx_early
+            i_b = (kd - tc.halfd) + mu;       // idx_mid
+            i_c = kd + mu;                    // idx_late
+            ok = cont && !(i_a < 0.0) && !(i_c + 1.0 >= lend);
+            r_a = __double2int_rz(i_a); r_b = __double2int_rz(i_b); r_c = __double2int_rz(i_c);
+            const bool inwin = (r_a >= win_lo) && (r_c + 1 < win_hi);
+            fast = !__any(odd || (ok && !inwin));
+        } else {
+            // hw1/gardner.py:45-53
+            const bool cont = gs.active && (gs.k < tc.n_symbols);
+            const double base = (double)(gs.k * sps);
+            i_a = base + mu;                                   // idx_k
+            i_c = (double)((gs.k + 1) * sps) + mu;             // idx_next
+            i_b = base + mu + tc.halfd;                        // idx_mid
+            ok = cont && !(i_c + 1.0 >= lend || i_b + 1.0 >= lend);
+            const double fa = dspm::d_floor(i_a), fb = dspm::d_floor(i_b), fc = dspm::d_floor(i_c);
+            r_a = __double2int_rz(fa); r_b = __double2int_rz(fb); r_c = __double2int_rz(fc);
+            const bool inwin = (r_a >= win_lo) && (r_c + 1 < win_hi) && (r_a >= 0);
+            fast = !__any(ok && !inwin);
+        }
+    }
+    if (fast) {
+        cd a0 = tl.lds_at(r_a), a1 = tl.lds_at(r_a + 1);
+        cd b0 = tl.lds_at(r_b), b1 = tl.lds_at(r_b + 1);
+        cd c0 = tl.lds_at(r_c), c1 = tl.lds_at(r_c + 1);
+        cd xa = dspm::lerp(a0, a1, i_a - (double)r_a);
+        cd xb = dspm::lerp(b0, b1, i_b - (double)r_b);
+        cd xc = dspm::lerp(c0, c1, i_c - (double)r_c);
+        const double e = dspm::ted_error(xa, xb, xc);
+        cd rec; rec.re = 0.0; rec.im = 0.0;
+        double mu_n, mu_hist;
+        if (VARIANT == DSP_VARIANT_GARDNER2) {
+            mu_n = mu - alpha * e;                              // :91
+            mu_hist = mu_n;
+            const double i_o = (double)gs.k + mu_n;             // :95
+            const int r_o = __double2int_rz(i_o);
+            const int hi_lim = win_hi < len ? win_hi : len;
+            const bool ofast = (i_o > -1.0e9 && i_o < 1.0e9) && r_o >= win_lo && r_o + 1 < hi_lim;
+            if (!__any(ok && !ofast)) {
+                rec = dspm::lerp(tl.lds_at(r_o), tl.lds_at(r_o + 1), i_o - (double)r_o);
+            } else if (ok) {
+                rec = dspm::g2_interp(i_o, len, (const dspm::LagrangeW *)nullptr, FetchFn<IN>{tl});
+            }
+            if (ok) gs.k += sps;                                // :98
+        } else {
+            mu_hist = mu;                                       // :63
+            rec = xa;                                           // :72
+            mu_n = mu + alpha * e;                              // :66
+            mu_n = mu_n < -spsd ? -spsd : mu_n;                 // :69
+            mu_n = mu_n > spsd ? spsd : mu_n;
+            if (ok) gs.k += 1;
+        }
+        gs.mu = ok ? mu_n : mu;
+        gs.active = ok;
+        go.produced = ok;
+        go.err = ok ? e : 0.0;
+        go.mu = ok ? mu_hist : 0.0;
+        go.rec.re = ok ? rec.re : 0.0;
+        go.rec.im = ok ? rec.im : 0.0;
+    } else {
+        if (VARIANT == DSP_VARIANT_GARDNER2)
+            go = dspm::gardner2_iter(gs, len, sps, alpha, Lp, FetchFn<IN>{tl});
+        else
+            go = dspm::ted_iter(gs, len, sps, tc.n_symbols, alpha, Lp, FetchFn<IN>{tl});
+    }
+    return go;
+}
+
+// FLL step for every lane, committed by select (no divergent control flow)
+struct FllLane { double sr, si, ef, freq; unsigned quad; };
+__device__ __forceinline__ FllLane fll_iter(const dspm::MathK &MK, bool pending, cd x, double idx,
+                                            double &freq, double &integ, double kp, double ki)
+{
+    double nf = freq, ni = integ;
+    dspm::FllOut fo = dspm::fll_step(MK, x.re, x.im, idx, nf, ni, kp, ki);
+    freq = pending ? nf : freq;
+    integ = pending ? ni : integ;
+    FllLane o;
+    o.sr = pending ? fo.sr : 0.0; o.si = pending ? fo.si : 0.0;
+    o.ef = pending ? fo.ef : 0.0; o.freq = pending ? fo.freq : 0.0;
+    o.quad = pending ? (unsigned)fo.quad : 0u;
+    return o;
+}
+
+template <typename IN>
+__device__ __forceinline__ void tile_init(Tile<IN> &tl, const SyncParams &P, unsigned char *ring,
+                                          int tile, int lane, double scale)
+{
+    tl.xt = (const IN *)P.x + (size_t)tile * P.in_rows * 64;
+    tl.ring = ring;
+    tl.lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)ring;
+    tl.lane = lane; tl.R = P.ring_rows; tl.RM = P.ring_rows - 1; tl.in_rows = P.in_rows;
+    tl.win_lo = 0; tl.win_hi = 0; tl.F = 0; tl.scale = scale;
+}
+
+__device__ __forceinline__ void timing_init(TimingConst &tc, dspm::GState &gs, const SyncParams &P,
+                                            int variant, int len, bool lane_ok)
+{
+    tc.len = len; tc.sps = P.sps; tc.spsd = (double)P.sps; tc.lend = (double)len; tc.alpha = P.alpha;
+    tc.halfd = variant == DSP_VARIANT_TED ? tc.spsd / 2.0 : (double)(P.sps / 2);
+    tc.n_symbols = 0;
+    gs.mu = variant == DSP_VARIANT_GARDNER2 ? P.mu0 : 0.0;
+    gs.k = variant == DSP_VARIANT_GARDNER2 ? P.sps : 0;
+    gs.active = lane_ok && len > 0;
+    if (variant == DSP_VARIANT_TED) {
+        int ns = len - 2 * P.sps;                       // (len - 2*sps)//sps, floor
+        tc.n_symbols = ns >= 0 ? ns / P.sps : -((-ns + P.sps - 1) / P.sps);
+        gs.active = lane_ok;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Unified kernel: one wave per tile does the timing loop and the FLL.
+template <typename IN, int VARIANT, bool FLL, bool LAGR>
+__global__ __launch_bounds__(64) void sync_kernel(SyncParams P)
+{
+    typedef typename InT<IN>::OS OS;     // output scalar (float for c64 in, double for c128 in)
+    typedef typename InT<IN>::OC OC;     // output complex
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int tile = blockIdx.x;
+    const int b = tile * 64 + lane;
+    const bool lane_ok = b < P.B;
+    const int len = lane_ok ? (P.lens ? P.lens[b] : P.len_all) : 0;
+    const double scale = (lane_ok && P.scale) ? P.scale[b] : 1.0;
+    const int out_rows = P.out_rows, sps = P.sps, T = P.T;
+    const int cap_rows = out_rows - 1;   // the last output row is scratch (uniform stores land there)
+    const size_t obase = (size_t)tile * out_rows * 64 + lane;
+    const bool ring = P.use_ring != 0;
+
+    Tile<IN> tl;
+    tile_init(tl, P, smem, tile, lane, scale);
+    if (ring) tl.prologue(sps, T, P.C);
 
     dspm::LagrangeW LW;
     const dspm::LagrangeW *Lp = nullptr;
     if (LAGR) { dspm::lagrange_weights(P.half_len, LW); Lp = &LW; }
 
-    // ---- per-lane loop state ------------------------------------------------
+    TimingConst tc;
     dspm::GState gs;
-    gs.mu = (VARIANT == DSP_VARIANT_GARDNER2) ? P.mu0 : 0.0;
-    gs.k = (VARIANT == DSP_VARIANT_GARDNER2) ? sps : 0;
-    gs.active = lane_ok && len > 0;
-    int n_symbols = 0;                   // ted: (len - 2*sps)//sps (floor)
-    if (VARIANT == DSP_VARIANT_TED) {
-        int ns = len - 2 * sps;
-        n_symbols = ns >= 0 ? ns / sps : -((-ns + sps - 1) / sps);
-        gs.active = lane_ok;
-    }
+    timing_init(tc, gs, P, VARIANT, len, lane_ok);
     double freq = 0.0, integ = 0.0, i0 = 0.0;
     if (FLL && lane_ok) {
         if (P.fll_in) { freq = P.fll_in[2 * b]; integ = P.fll_in[2 * b + 1]; }
         if (P.i0) i0 = P.i0[b];
     }
-    const double kp = P.kp, ki = P.ki, alpha = P.alpha;
+    const double kp = P.kp, ki = P.ki;
     dspm::MathK MK;
     if (FLL) MK = load_math_consts();
 
@@ -183,155 +351,51 @@ __global__ __launch_bounds__(64) void sync_kernel(SyncParams P)
     cd rec_prev; rec_prev.re = 0.0; rec_prev.im = 0.0;
     int n_rec = 0;
     if (VARIANT != DSP_VARIANT_TED) {
-        if (gs.active) { rec_prev = fetch(0); pending = true; n_rec = 1; }
+        if (gs.active) { rec_prev = tl.fetch(0); pending = true; n_rec = 1; }
         if (VARIANT == DSP_VARIANT_GARDNER2 && o_rec) st_cplx(o_rec + obase, rec_prev.re, rec_prev.im);
     }
     if (VARIANT == DSP_VARIANT_NONE) gs.active = false;
     bool overflow = false;
 
-    // straight-line LDS access for the fast path (row known to be inside the ring window)
-    auto lds_at = [&](int row) -> cd {
-        IN v = ((const IN *)smem)[(row & RM) * 64 + lane];
-        cd z;
-        z.re = (double)v.x * scale;
-        z.im = (double)v.y * scale;
-        return z;
-    };
-    const double spsd = (double)sps, lend = (double)len;
-    const double halfd = (VARIANT == DSP_VARIANT_TED) ? spsd / 2.0 : (double)(sps / 2);
-
     int it = 0;
     bool running = true;
     for (int blk = 0; running; blk++) {
-        if (ring) {
-            if (blk > 0) wait_vmcnt(P.nwait);   // the previous block's DMA has landed
-            win_hi = F;
-            issue(sps * (blk + 2) * T + P.C);
-            win_lo = F - R > 0 ? F - R : 0;
-        }
+        if (ring) tl.advance(blk, sps, T, P.C, P.nwait);
         for (int t = 0; t < T; t++, it++) {
             bool more = (VARIANT == DSP_VARIANT_NONE) ? pending : (gs.active || (FLL && pending));
             if (!__any(more)) { running = false; break; }
             const int rec_row = (VARIANT == DSP_VARIANT_TED) ? it : it + 1;
             const int fll_row = it - ROFF;
-            if (fll_row >= out_rows) { running = false; break; }      // capacity (uniform)
+            if (fll_row >= cap_rows) { running = false; break; }      // capacity (uniform)
 
-            // ---- FLL on the symbol appended by the previous iteration: computed by every
-            //      lane, committed by select (no divergent control flow) ----------------
-            double f_sr = 0.0, f_si = 0.0, f_ef = 0.0, f_freq = 0.0;
-            unsigned f_quad = 0;
-            if (FLL) {
-                double nf = freq, ni = integ;
-                dspm::FllOut fo = dspm::fll_step(MK, rec_prev.re, rec_prev.im, (double)fll_row + i0,
-                                                 nf, ni, kp, ki);
-                freq = pending ? nf : freq;
-                integ = pending ? ni : integ;
-                f_sr = pending ? fo.sr : 0.0; f_si = pending ? fo.si : 0.0;
-                f_ef = pending ? fo.ef : 0.0; f_freq = pending ? fo.freq : 0.0;
-                f_quad = pending ? (unsigned)fo.quad : 0u;
-            }
+            FllLane fo; fo.sr = 0.0; fo.si = 0.0; fo.ef = 0.0; fo.freq = 0.0; fo.quad = 0;
+            if (FLL) fo = fll_iter(MK, pending, rec_prev, (double)fll_row + i0, freq, integ, kp, ki);
 
-            // ---- timing loop: one pass of the reference's loop body --------
             dspm::GOut go; go.produced = false; go.rec.re = 0.0; go.rec.im = 0.0; go.err = 0.0; go.mu = 0.0;
             if (VARIANT == DSP_VARIANT_NONE) {
                 const bool have = pending && (it + 1 < len);
-                if (it + 1 >= win_lo && it + 1 < win_hi) {            // uniform
-                    cd v = lds_at(it + 1);
+                if (it + 1 >= tl.win_lo && it + 1 < tl.win_hi) {            // uniform
+                    cd v = tl.lds_at(it + 1);
                     go.rec.re = have ? v.re : 0.0; go.rec.im = have ? v.im : 0.0;
                 } else if (have) {
-                    go.rec = fetch(it + 1);
+                    go.rec = tl.fetch(it + 1);
                 }
                 go.produced = have;
             } else {
-                if (gs.active && rec_row >= out_rows) { gs.active = false; overflow = true; }
-                bool fast = !LAGR;
-                bool ok = false;
-                double mu = gs.mu, i_a = 0.0, i_b = 0.0, i_c = 0.0;
-                int r_a = 0, r_b = 0, r_c = 0;
-                if (!LAGR) {
-                    if (VARIANT == DSP_VARIANT_GARDNER2) {
-                        // gardner2.py:63-80 without the wrap loops (a lane that needs them, or
-                        // rows outside the ring, sends the wave down the generic path)
-                        const bool cont = gs.active && (gs.k <= len - sps);
-                        const double kd = (double)gs.k;
-                        const bool odd = cont && !(mu < spsd && mu >= -spsd);   // wrap or NaN
-                        i_a = (kd - spsd) + mu;           // idx_early
-                        i_b = (kd - halfd) + mu;          // idx_mid
-                        i_c = kd + mu;                    // idx_late
-                        ok = cont && !(i_a < 0.0) && !(i_c + 1.0 >= lend);
-                        r_a = __double2int_rz(i_a); r_b = __double2int_rz(i_b); r_c = __double2int_rz(i_c);
-                        const bool inwin = (r_a >= win_lo) && (r_c + 1 < win_hi);
-                        fast = !__any(odd || (ok && !inwin));
-                    } else {
-                        // hw1/gardner.py:45-53
-                        const bool cont = gs.active && (gs.k < n_symbols);
-                        const double base = (double)(gs.k * sps);
-                        i_a = base + mu;                                   // idx_k
-                        i_c = (double)((gs.k + 1) * sps) + mu;             // idx_next
-                        i_b = base + mu + halfd;                           // idx_mid
-                        ok = cont && !(i_c + 1.0 >= lend || i_b + 1.0 >= lend);
-                        const double fa = dspm::d_floor(i_a), fb = dspm::d_floor(i_b), fc = dspm::d_floor(i_c);
-                        r_a = __double2int_rz(fa); r_b = __double2int_rz(fb); r_c = __double2int_rz(fc);
-                        const bool inwin = (r_a >= win_lo) && (r_c + 1 < win_hi) && (r_a >= 0);
-                        fast = !__any(ok && !inwin);
-                    }
-                }
-                if (fast) {
-                    cd a0 = lds_at(r_a), a1 = lds_at(r_a + 1);
-                    cd b0 = lds_at(r_b), b1 = lds_at(r_b + 1);
-                    cd c0 = lds_at(r_c), c1 = lds_at(r_c + 1);
-                    cd xa = dspm::lerp(a0, a1, i_a - (double)r_a);
-                    cd xb = dspm::lerp(b0, b1, i_b - (double)r_b);
-                    cd xc = dspm::lerp(c0, c1, i_c - (double)r_c);
-                    const double e = dspm::ted_error(xa, xb, xc);
-                    cd rec; rec.re = 0.0; rec.im = 0.0;
-                    double mu_n, mu_hist;
-                    if (VARIANT == DSP_VARIANT_GARDNER2) {
-                        mu_n = mu - alpha * e;                              // :91
-                        mu_hist = mu_n;
-                        const double i_o = (double)gs.k + mu_n;             // :95
-                        const int r_o = __double2int_rz(i_o);
-                        const int hi_lim = win_hi < len ? win_hi : len;
-                        const bool ofast = (i_o > -1.0e9 && i_o < 1.0e9) && r_o >= win_lo && r_o + 1 < hi_lim;
-                        if (!__any(ok && !ofast)) {
-                            rec = dspm::lerp(lds_at(r_o), lds_at(r_o + 1), i_o - (double)r_o);
-                        } else if (ok) {
-                            rec = dspm::g2_interp(i_o, len, (const dspm::LagrangeW *)nullptr, fetch);
-                        }
-                        if (ok) gs.k += sps;                                // :98
-                    } else {
-                        mu_hist = mu;                                       // :63
-                        rec = xa;                                           // :72
-                        mu_n = mu + alpha * e;                              // :66
-                        mu_n = mu_n < -spsd ? -spsd : mu_n;                 // :69
-                        mu_n = mu_n > spsd ? spsd : mu_n;
-                        if (ok) gs.k += 1;
-                    }
-                    gs.mu = ok ? mu_n : mu;
-                    gs.active = ok;
-                    go.produced = ok;
-                    go.err = ok ? e : 0.0;
-                    go.mu = ok ? mu_hist : 0.0;
-                    go.rec.re = ok ? rec.re : 0.0;
-                    go.rec.im = ok ? rec.im : 0.0;
-                } else {
-                    if (VARIANT == DSP_VARIANT_GARDNER2)
-                        go = dspm::gardner2_iter(gs, len, sps, alpha, Lp, fetch);
-                    else
-                        go = dspm::ted_iter(gs, len, sps, n_symbols, alpha, Lp, fetch);
-                }
+                if (gs.active && rec_row >= cap_rows) { gs.active = false; overflow = true; }
+                go = timing_iter<IN, VARIANT, LAGR>(tl, gs, tc, Lp);
             }
             // ---- stores: unconditional, one instruction per enabled output -
             const int frow = fll_row < 0 ? 0 : fll_row;
             const size_t fo_off = obase + (size_t)frow * 64;
             if (FLL) {
-                if (o_sig) st_cplx(o_sig + fo_off, f_sr, f_si);
-                if (o_freq) st_val(o_freq + fo_off, f_freq);
-                if (o_ef) st_val(o_ef + fo_off, f_ef);
-                if (o_dec) st_b8(o_dec + fo_off, f_quad);
+                if (o_sig) st_cplx(o_sig + fo_off, fo.sr, fo.si);
+                if (o_freq) st_val(o_freq + fo_off, fo.freq);
+                if (o_ef) st_val(o_ef + fo_off, fo.ef);
+                if (o_dec) st_b8(o_dec + fo_off, fo.quad);
             }
             if (VARIANT != DSP_VARIANT_NONE) {
-                const int rrow = rec_row < out_rows ? rec_row : out_rows - 1;
+                const int rrow = rec_row < cap_rows ? rec_row : cap_rows;   // last row = scratch
                 const size_t g_off = obase + (size_t)it * 64;
                 if (o_rec) st_cplx(o_rec + obase + (size_t)rrow * 64, go.rec.re, go.rec.im);
                 if (o_terr) st_val(o_terr + g_off, go.err);
@@ -348,6 +412,134 @@ __global__ __launch_bounds__(64) void sync_kernel(SyncParams P)
         if (P.n_out) P.n_out[b] = n_rec;
         if (P.status) P.status[b] = overflow ? 1 : 0;
         if (FLL && P.fll_out) { P.fll_out[2 * b] = freq; P.fll_out[2 * b + 1] = integ; }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Split kernel: two waves per tile.  Wave 0 runs the timing loop (ring, DMA,
+// rec/err/mu stores) and hands each recovered symbol to wave 1 through a
+// double-buffered LDS queue; wave 1 runs the FLL, the slicer and their stores
+// one queue block behind.  The two recurrences are independent chains, so
+// giving each its own wave doubles the waves per SIMD for the same bursts and
+// halves the per-wave instruction stream (the kernel is issue/latency bound:
+// one wave issues at most one instruction per 4 cycles).
+//   LDS: [ring][queue 2*TQ*64 complex128][flags 2*TQ*64 bytes][more[2]]
+//   Block qb: wave 0 fills queue[qb&1], s_barrier; wave 1 drains it while wave 0
+//   fills the other half.  Every block both waves execute exactly one barrier.
+template <typename IN, int VARIANT>
+__global__ __launch_bounds__(128) void sync_split_kernel(SyncParams P)
+{
+    typedef typename InT<IN>::OS OS;
+    typedef typename InT<IN>::OC OC;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0 = timing, 1 = FLL
+    const int tile = blockIdx.x;
+    const int b = tile * 64 + lane;
+    const bool lane_ok = b < P.B;
+    const int len = lane_ok ? (P.lens ? P.lens[b] : P.len_all) : 0;
+    const double scale = (lane_ok && P.scale) ? P.scale[b] : 1.0;
+    const int out_rows = P.out_rows, sps = P.sps, T = P.T, TQ = P.TQ;
+    const int cap_rows = out_rows - 1;   // the last output row is scratch
+    const size_t obase = (size_t)tile * out_rows * 64 + lane;
+    const bool ring = P.use_ring != 0;
+
+    unsigned char *q_base = smem + (size_t)P.ring_rows * 64 * sizeof(IN) * (ring ? 1 : 0);
+    d2v *q_data = (d2v *)q_base;                                    // [2][TQ][64]
+    unsigned char *q_flag = q_base + (size_t)2 * TQ * 64 * sizeof(d2v);   // [2][TQ][64]
+    volatile int *q_more = (volatile int *)(q_flag + (size_t)2 * TQ * 64);   // [2]
+    constexpr int ROFF = (VARIANT == DSP_VARIANT_TED) ? 0 : 1;      // FLL row of queue entry `it` = it + ROFF
+
+    if (role == 0) {
+        // =================== timing wave ===================
+        Tile<IN> tl;
+        tile_init(tl, P, smem, tile, lane, scale);
+        if (ring) tl.prologue(sps, T, P.C);
+        TimingConst tc;
+        dspm::GState gs;
+        timing_init(tc, gs, P, VARIANT, len, lane_ok);
+        OC *o_rec = (OC *)P.rec; OS *o_terr = (OS *)P.terr; OS *o_mu = (OS *)P.mu;
+        int n_rec = 0;
+        if (VARIANT == DSP_VARIANT_GARDNER2) {
+            cd r0; r0.re = 0.0; r0.im = 0.0;
+            if (gs.active) { r0 = tl.fetch(0); n_rec = 1; }
+            if (o_rec) st_cplx(o_rec + obase, r0.re, r0.im);
+        }
+        bool overflow = false;
+        const int m = T / TQ;                 // queue blocks per DMA block
+        int it = 0;
+        for (int qb = 0;; qb++) {
+            if (ring && (qb % m) == 0) tl.advance(qb / m, sps, T, P.C, P.nwait);
+            const int buf = qb & 1;
+            for (int t = 0; t < TQ; t++, it++) {
+                const int rec_row = it + ROFF;
+                if (gs.active && rec_row >= cap_rows) { gs.active = false; overflow = true; }
+                dspm::GOut go = timing_iter<IN, VARIANT, false>(tl, gs, tc, nullptr);
+                const int rrow = rec_row < cap_rows ? rec_row : cap_rows;
+                const int erow = it < cap_rows ? it : cap_rows;
+                const size_t g_off = obase + (size_t)erow * 64;
+                if (o_rec) st_cplx(o_rec + obase + (size_t)rrow * 64, go.rec.re, go.rec.im);
+                if (o_terr) st_val(o_terr + g_off, go.err);
+                if (o_mu) st_val(o_mu + g_off, go.mu);
+                d2v qv = {go.rec.re, go.rec.im};
+                q_data[(buf * TQ + t) * 64 + lane] = qv;
+                q_flag[(buf * TQ + t) * 64 + lane] = go.produced ? 1 : 0;
+                n_rec += go.produced ? 1 : 0;
+            }
+            const bool more = __any(gs.active);
+            if (lane == 0) q_more[buf] = more ? 1 : 0;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (!more) break;
+        }
+        if (lane_ok) {
+            if (P.n_out) P.n_out[b] = n_rec;
+            if (P.status) P.status[b] = overflow ? 1 : 0;
+        }
+    } else {
+        // =================== FLL wave ===================
+        const IN *xt = (const IN *)P.x + (size_t)tile * P.in_rows * 64;
+        double freq = 0.0, integ = 0.0, i0 = 0.0;
+        if (lane_ok) {
+            if (P.fll_in) { freq = P.fll_in[2 * b]; integ = P.fll_in[2 * b + 1]; }
+            if (P.i0) i0 = P.i0[b];
+        }
+        const double kp = P.kp, ki = P.ki;
+        const dspm::MathK MK = load_math_consts();
+        OC *o_sig = (OC *)P.sig; OS *o_freq = (OS *)P.freq; OS *o_ef = (OS *)P.ef;
+        uint8_t *o_dec = P.dec;
+        if (VARIANT == DSP_VARIANT_GARDNER2) {       // recovered[0] = signal[0]
+            const bool have = lane_ok && len > 0;
+            IN v = xt[lane];
+            cd r0; r0.re = (double)v.x * scale; r0.im = (double)v.y * scale;
+            FllLane fo = fll_iter(MK, have, r0, i0, freq, integ, kp, ki);
+            if (o_sig) st_cplx(o_sig + obase, fo.sr, fo.si);
+            if (o_freq) st_val(o_freq + obase, fo.freq);
+            if (o_ef) st_val(o_ef + obase, fo.ef);
+            if (o_dec) st_b8(o_dec + obase, fo.quad);
+        }
+        int it = 0;
+        for (int qb = 0;; qb++) {
+            const int buf = qb & 1;
+            asm volatile("s_barrier" ::: "memory");
+            const int more = q_more[buf];
+            for (int t = 0; t < TQ; t++, it++) {
+                const int row = it + ROFF;
+                d2v qv = q_data[(buf * TQ + t) * 64 + lane];
+                const bool pend = q_flag[(buf * TQ + t) * 64 + lane] != 0;
+                cd x; x.re = qv.x; x.im = qv.y;
+                if (row < cap_rows) {                                    // uniform
+                    FllLane fo = fll_iter(MK, pend, x, (double)row + i0, freq, integ, kp, ki);
+                    const size_t off = obase + (size_t)row * 64;
+                    if (o_sig) st_cplx(o_sig + off, fo.sr, fo.si);
+                    if (o_freq) st_val(o_freq + off, fo.freq);
+                    if (o_ef) st_val(o_ef + off, fo.ef);
+                    if (o_dec) st_b8(o_dec + off, fo.quad);
+                }
+            }
+            if (!more) break;
+        }
+        if (lane_ok && P.fll_out) { P.fll_out[2 * b] = freq; P.fll_out[2 * b + 1] = integ; }
     }
 }
 
@@ -396,6 +588,14 @@ static hipError_t launch_v(const SyncParams &P, size_t lds, hipStream_t s)
 template <typename IN>
 static hipError_t launch_in(const SyncParams &P, int variant, bool fll, size_t lds, hipStream_t s)
 {
+    if (P.TQ > 0) {        // two waves per tile (timing wave + FLL wave)
+        int ntiles = (P.B + 63) / 64;
+        if (variant == DSP_VARIANT_GARDNER2)
+            hipLaunchKernelGGL((sync_split_kernel<IN, DSP_VARIANT_GARDNER2>), dim3(ntiles), dim3(128), lds, s, P);
+        else
+            hipLaunchKernelGGL((sync_split_kernel<IN, DSP_VARIANT_TED>), dim3(ntiles), dim3(128), lds, s, P);
+        return hipGetLastError();
+    }
     switch (variant) {
         case DSP_VARIANT_GARDNER2:
             return fll ? launch_v<IN, DSP_VARIANT_GARDNER2, true>(P, lds, s)

@@ -49,7 +49,7 @@ void dsp_destroy(dsp_ctx *ctx);
 const char *dsp_last_error(void);
 int dsp_set_stream(dsp_ctx *ctx, void *hip_stream);      /* adopt an external hipStream_t */
 int dsp_synchronize(dsp_ctx *ctx);
-int dsp_set_option(dsp_ctx *ctx, const char *name, int64_t value); /* "ring_rows", "lds_pad" */
+int dsp_set_option(dsp_ctx *ctx, const char *name, int64_t value); /* "ring_rows", "lds_pad", "split" */
 
 /* ---- device memory and timing (for *_dev pipelines and bench.py) ---------- */
 int dsp_malloc(dsp_ctx *ctx, size_t bytes, void **dptr);
@@ -129,7 +129,7 @@ typedef struct dsp_sync_args {
     double *fll_state_out;        /* [B][2] or NULL                                  */
     void *rec, *err, *mu, *sig, *freq, *ef;   /* tiles [..][out_rows][64] or NULL    */
     uint8_t *dec;
-    int64_t out_rows;
+    int64_t out_rows;       /* rows of every output; the LAST row is scratch: capacity = out_rows-1 */
     int32_t *n_out;         /* [B] or NULL                                           */
     int32_t *status;        /* [B] or NULL; bit0 = capacity reached                  */
 } dsp_sync_args;
