@@ -8,13 +8,17 @@ Everything numeric runs in libdsp_hip.so (hand-written HIP, see dsp_amd/csrc);
 importing the package does not need a GPU, calling a device function does.
 """
 from ._lib import (Context, DspError, default_context, build, lib, LIB_PATH,  # noqa: F401
-                   DSP_C64, DSP_C128, DSP_GARDNER2, DSP_GARDNER_TED, DSP_FLL_ONLY)
+                   DSP_C64, DSP_C128, DSP_I16, DSP_GARDNER2, DSP_GARDNER_TED, DSP_FLL_ONLY)
 from .api import (rrc_filter, fll_gains, interpolate_sample, gardner_timing_recovery,  # noqa: F401
-                  gardner_ted, fll_func, gardner_batch, fll_batch, sync_chain_batch)
+                  gardner_ted, fll_func, gardner_batch, fll_batch, sync_chain_batch,
+                  read_iq_int16, read_iq_int16_words, read_iq_float32, fir_batch, filter_samples,
+                  rx_chain_batch)
 
 __all__ = [
     "Context", "DspError", "default_context", "build", "lib",
     "rrc_filter", "fll_gains", "interpolate_sample",
     "gardner_timing_recovery", "gardner_ted", "fll_func",
     "gardner_batch", "fll_batch", "sync_chain_batch",
+    "read_iq_int16", "read_iq_int16_words", "read_iq_float32", "fir_batch", "filter_samples",
+    "rx_chain_batch",
 ]

@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DSP_HIP_LIB", os.path.join(_HERE, "libdsp_hip.so"))
 
-DSP_C64, DSP_C128 = 0, 1
+DSP_C64, DSP_C128, DSP_I16 = 0, 1, 2
 DSP_GARDNER2, DSP_GARDNER_TED, DSP_FLL_ONLY = 0, 1, 2
 DSP_E_CAPACITY = -3
 
@@ -38,6 +38,18 @@ class SyncArgs(C.Structure):
         ("rec", C.c_void_p), ("err", C.c_void_p), ("mu", C.c_void_p), ("sig", C.c_void_p),
         ("freq", C.c_void_p), ("ef", C.c_void_p), ("dec", C.c_void_p),
         ("out_rows", C.c_int64), ("n_out", C.c_void_p), ("status", C.c_void_p),
+    ]
+
+
+class FirArgs(C.Structure):
+    """struct dsp_fir_args of include/dsp_hip.h"""
+    _fields_ = [
+        ("src", C.c_void_p), ("in_kind", C.c_int32), ("start", C.c_int32),
+        ("B", C.c_int64), ("N", C.c_int64), ("src_stride", C.c_int64),
+        ("lens", C.c_void_p), ("h", C.c_void_p), ("n_taps", C.c_int32), ("reserved", C.c_int32),
+        ("in_scale", C.c_void_p), ("tiles", C.c_void_p), ("rows", C.c_int64),
+        ("scale", C.c_void_p), ("std_out", C.c_void_p), ("inv_std_out", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 
@@ -100,11 +112,20 @@ def _declare(L):
     L.dsp_tile_bursts_dev.argtypes = [vp, vp, ci, i64, i64, i64, vp, vp, i64]
     L.dsp_untile_dev.argtypes = [vp, vp, ci, i64, i64, vp, i64, i64]
     L.dsp_sync_tiles_dev.argtypes = [vp, C.POINTER(SyncArgs)]
+    L.dsp_load_iq_i16.argtypes = [vp, vp, i64, ci, vp, C.POINTER(i64)]
+    L.dsp_load_iq_f32.argtypes = [vp, vp, i64, vp, C.POINTER(i64)]
+    L.dsp_fir_same_std.argtypes = [vp, vp, ci, i64, i64, i64, vp, vp, ci, ci, ci, vp, i64, vp]
+    L.dsp_rx_chain.argtypes = [vp, vp, ci, i64, i64, i64, vp, ci, vp, ci, ci, ci, dbl, dbl, ci, ci,
+                               dbl, dbl, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]
+    L.dsp_fir_workspace_bytes.argtypes = [ci, i64, i64, ci]
+    L.dsp_fir_workspace_bytes.restype = i64
+    L.dsp_fir_tiles_dev.argtypes = [vp, C.POINTER(FirArgs)]
     for name in ("dsp_device_count", "dsp_create", "dsp_set_stream", "dsp_synchronize",
                  "dsp_set_option", "dsp_malloc", "dsp_free", "dsp_memset", "dsp_h2d", "dsp_d2h",
                  "dsp_timer_start", "dsp_timer_stop", "dsp_rrc_taps", "dsp_fll_gains",
                  "dsp_gardner", "dsp_fll", "dsp_sync_chain", "dsp_tile_bursts_dev",
-                 "dsp_untile_dev", "dsp_sync_tiles_dev"):
+                 "dsp_untile_dev", "dsp_sync_tiles_dev", "dsp_load_iq_i16", "dsp_load_iq_f32",
+                 "dsp_fir_same_std", "dsp_rx_chain", "dsp_fir_tiles_dev"):
         getattr(L, name).restype = ci
 
 

@@ -24,7 +24,8 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import DSP_C64, DSP_C128, DSP_GARDNER2, DSP_GARDNER_TED, check, default_context
+from ._lib import (DSP_C64, DSP_C128, DSP_I16, DSP_GARDNER2, DSP_GARDNER_TED, check,
+                   default_context)
 
 
 def _vp(a):
@@ -217,3 +218,114 @@ def fll_func(signal, Bn=0.001, y=1):
     x = x.astype(np.complex128, copy=False)
     out, cf, freq, ef, _ = fll_batch(x[None, :], Bn, y)
     return out[0].copy(), float(cf[0]), freq[0].copy(), ef[0].copy()
+
+
+# ---------------------------------------------------------------------------
+# loaders and matched filter
+def read_iq_int16_words(raw, normalize=True, *, ctx=None):
+    """read_iq_int16 on an in-memory int16 word buffer (hw1/gardner.py:79-91)."""
+    ctx = ctx or default_context()
+    raw = np.ascontiguousarray(raw, dtype=np.int16)
+    if raw.size < 2:
+        raise ValueError("need at least one I/Q pair")                       # hw1/gardner.py:80-81
+    out = np.empty(raw.size // 2, dtype=np.complex64)
+    n = C.c_int64()
+    check(_lib.lib().dsp_load_iq_i16(ctx.handle, _vp(raw), raw.size, int(bool(normalize)), _vp(out),
+                                     C.byref(n)))
+    return out[:n.value]
+
+
+def read_iq_int16(path, normalize=True):
+    """Drop-in for read_iq_int16(path, normalize=True) (hw1/gardner.py:77-91)."""
+    return read_iq_int16_words(np.fromfile(path, dtype=np.int16), normalize)
+
+
+def read_iq_float32(path):
+    """The float32 loader idiom s[::2] + 1j*s[1::2] (read_file.py:108-109) -> complex64."""
+    raw = np.ascontiguousarray(np.fromfile(path, dtype=np.float32))
+    out = np.empty(raw.size // 2, dtype=np.complex64)
+    n = C.c_int64()
+    check(_lib.lib().dsp_load_iq_f32(None, _vp(raw), raw.size, _vp(out), C.byref(n)))
+    return out[:n.value]
+
+
+def fir_batch(x, taps, *, normalize=True, start=-1, lens=None, want_std=False, ctx=None):
+    """y = np.convolve(x[b], taps, 'same') [/ np.std(y)] for every burst (worker.py:173-178).
+
+    start=-1 is mode='same'; start=len(taps)//2 is apply_filter of hw1/test_rrc_cascade.py:103-108.
+    """
+    ctx = ctx or default_context()
+    x, dt, rdt = _as_bursts(x)
+    B, N = x.shape
+    h = np.ascontiguousarray(taps, dtype=np.float64)
+    if h.ndim != 1 or h.size < 1:
+        raise ValueError("taps must be a non-empty vector")
+    if h.size > N:
+        raise ValueError("len(taps) > len(x): np.convolve would swap its operands")
+    lens = _lens(lens, B, N)
+    y = np.zeros_like(x)
+    std = np.zeros(B, dtype=np.float64)
+    check(_lib.lib().dsp_fir_same_std(ctx.handle, _vp(x), dt, B, N, N, _vp(lens), _vp(h), h.size,
+                                      int(start), int(bool(normalize)), _vp(y), N, _vp(std)))
+    return (y, std) if want_std else y
+
+
+def filter_samples(samples, sps=4, span=10, alpha=0.35):
+    """Drop-in for Processing.filter_samples (worker.py:173-178): RRC 'same' then / np.std."""
+    x = np.asarray(samples)
+    if x.ndim != 1:
+        raise ValueError("samples must be one-dimensional")
+    h = rrc_filter(sps, span, alpha)
+    x = x.astype(np.complex128, copy=False)
+    return fir_batch(x[None, :], h, normalize=True)[0]
+
+
+def rx_chain_batch(x, taps, sps=4, alpha=0.007, mu_initial=0.0, Bn=0.03, y=1, *, variant=DSP_GARDNER2,
+                   lens=None, normalize_peak=True, normalize_std=True, interp_half_len=0,
+                   outputs="all", capacity=None, ctx=None):
+    """Raw bursts -> RRC 'same' -> /std -> Gardner -> FLL -> decisions (worker.py:299-304).
+
+    x: [B, N] int16 pairs ([B, N, 2] or [B, 2N] int16), complex64 or complex128.
+    Returns a dict of [B, cap] arrays plus "n_out" and "std".
+    """
+    ctx = ctx or default_context()
+    x = np.asarray(x)
+    if x.dtype == np.int16:
+        if x.ndim == 3 and x.shape[2] == 2:
+            x = x.reshape(x.shape[0], -1)
+        if x.ndim != 2 or x.shape[1] % 2:
+            raise ValueError("int16 input must be [B, 2N] interleaved I,Q")
+        x = np.ascontiguousarray(x)
+        B, N = x.shape[0], x.shape[1] // 2
+        kind, cdt, rdt = DSP_I16, np.complex64, np.float32
+    else:
+        x, kind, rdt = _as_bursts(x)
+        B, N = x.shape
+        cdt = x.dtype
+    h = np.ascontiguousarray(taps, dtype=np.float64)
+    sps = int(sps)
+    lens = _lens(lens, B, N)
+    names = ("rec", "err", "mu", "sig", "freq", "ef", "dec") if outputs == "all" else tuple(outputs)
+    cap = int(capacity) if capacity else N // sps + 8
+    L = _lib.lib()
+    for attempt in range(2):
+        bufs = {}
+        for nm in names:
+            dtp = cdt if nm in ("rec", "sig") else (np.uint8 if nm == "dec" else rdt)
+            bufs[nm] = np.zeros((B, cap), dtype=dtp)
+        n_out = np.zeros(B, dtype=np.int32)
+        std = np.zeros(B, dtype=np.float64)
+        g = lambda nm: _vp(bufs.get(nm))  # noqa: E731
+        rc = L.dsp_rx_chain(ctx.handle, _vp(x), kind, B, N, N, _vp(lens), int(bool(normalize_peak)),
+                            _vp(h), h.size, int(bool(normalize_std)), sps, float(alpha),
+                            float(mu_initial), int(variant), int(interp_half_len), float(Bn), float(y),
+                            g("rec"), g("err"), g("mu"), g("sig"), g("freq"), g("ef"), g("dec"),
+                            _vp(n_out), cap, _vp(std))
+        if rc == _lib.DSP_E_CAPACITY and attempt == 0 and capacity is None:
+            cap *= 4
+            continue
+        check(rc)
+        break
+    bufs["n_out"] = n_out
+    bufs["std"] = std
+    return bufs

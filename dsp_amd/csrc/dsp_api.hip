@@ -359,43 +359,20 @@ int dsp_untile_dev(dsp_ctx *c, const void *d_tiles, int elem_bytes, int64_t rows
 }
 
 // ---------------------------------------------------------------------------
-// Host-pointer orchestration shared by dsp_gardner / dsp_fll / dsp_sync_chain.
-struct HostOut { void *h; int elem; };
-
-static int run_host(dsp_ctx *c, const void *x, int dtype, int64_t B, int64_t N, int64_t x_stride,
-                    const int32_t *lens, const double *scale, int sps, double alpha, double mu0,
-                    int variant, int half_len, bool fll, double Bn, double y, const double *i0,
-                    const double *st_in, double *st_out, void *rec, void *err, void *mu, void *sig,
-                    void *freq, void *ef, uint8_t *dec, int32_t *n_out, int64_t out_stride)
+// Host-pointer orchestration shared by dsp_gardner / dsp_fll / dsp_sync_chain / dsp_rx_chain:
+// runs the recurrence kernel on device tiles and brings the requested outputs back as
+// burst-major host arrays.
+static int sync_to_host(dsp_ctx *c, const void *d_xt, int dtype, int64_t B, int64_t N, int64_t rows,
+                        const int32_t *d_lens, const double *d_scale, int sps, double alpha, double mu0,
+                        int variant, int half_len, bool fll, double Bn, double y, const double *i0,
+                        const double *st_in, double *st_out, void *rec, void *err, void *mu, void *sig,
+                        void *freq, void *ef, uint8_t *dec, int32_t *n_out, int64_t out_stride)
 {
-    if (!c) return fail(DSP_E_ARG, "ctx is NULL");
-    if (B < 0 || N < 0) return fail(DSP_E_ARG, "negative B or N");
-    if (B == 0) return DSP_OK;
-    if (!x) return fail(DSP_E_ARG, "x is NULL");
-    if (x_stride < N) return fail(DSP_E_ARG, "x_stride < N");
-    if (out_stride < 1) return fail(DSP_E_ARG, "out_stride < 1");
-    if (lens)
-        for (int64_t b = 0; b < B; b++)
-            if (lens[b] < 0 || lens[b] > N) return fail(DSP_E_ARG, "lens[%lld] out of range", (long long)b);
-    HIP_TRY(hipSetDevice(c->device));
     const int ce = dtype == DSP_C128 ? 16 : 8, re = ce / 2;
-    const int64_t rows = dsp_tile_rows(N);
     const int64_t ntiles = (B + 63) / 64;
     const int64_t out_rows = out_stride + 1;      // + the kernels' scratch row
     hipStream_t s = c->stream;
-
-    DevBuf d_x, d_xt, d_lens, d_scale, d_i0, d_stin, d_stout, d_nout, d_status, d_stage;
-    HIP_TRY(d_x.alloc((size_t)B * x_stride * ce));
-    HIP_TRY(d_xt.alloc((size_t)ntiles * rows * 64 * ce));
-    HIP_TRY(hipMemcpyAsync(d_x.p, x, (size_t)B * x_stride * ce, hipMemcpyHostToDevice, s));
-    if (lens) {
-        HIP_TRY(d_lens.alloc((size_t)B * 4));
-        HIP_TRY(hipMemcpyAsync(d_lens.p, lens, (size_t)B * 4, hipMemcpyHostToDevice, s));
-    }
-    if (scale) {
-        HIP_TRY(d_scale.alloc((size_t)B * 8));
-        HIP_TRY(hipMemcpyAsync(d_scale.p, scale, (size_t)B * 8, hipMemcpyHostToDevice, s));
-    }
+    DevBuf d_i0, d_stin, d_stout, d_nout, d_status, d_stage;
     if (i0) {
         HIP_TRY(d_i0.alloc((size_t)B * 8));
         HIP_TRY(hipMemcpyAsync(d_i0.p, i0, (size_t)B * 8, hipMemcpyHostToDevice, s));
@@ -407,8 +384,6 @@ static int run_host(dsp_ctx *c, const void *x, int dtype, int64_t B, int64_t N, 
     if (st_out) HIP_TRY(d_stout.alloc((size_t)B * 16));
     HIP_TRY(d_nout.alloc((size_t)B * 4));
     HIP_TRY(d_status.alloc((size_t)B * 4));
-    HIP_TRY(launch_tile_from_bursts(d_x.p, x_stride, d_lens.as<int>(), (int)N, (int)B, d_xt.p, (int)rows,
-                                    ce, s));
 
     struct OutSpec { void *host; int elem; DevBuf tiles; };
     OutSpec outs[7] = {{rec, ce, {}}, {err, re, {}}, {mu, re, {}}, {sig, ce, {}},
@@ -417,13 +392,14 @@ static int run_host(dsp_ctx *c, const void *x, int dtype, int64_t B, int64_t N, 
     for (auto &o : outs)
         if (o.host) {
             HIP_TRY(o.tiles.alloc((size_t)ntiles * out_rows * 64 * o.elem));
+            HIP_TRY(hipMemsetAsync(o.tiles.p, 0, (size_t)ntiles * out_rows * 64 * o.elem, s));
             if ((size_t)o.elem > max_elem) max_elem = o.elem;
         }
 
     dsp_sync_args a;
     memset(&a, 0, sizeof(a));
-    a.x = d_xt.p; a.dtype = dtype; a.variant = variant; a.B = B; a.N = N; a.in_rows = rows;
-    a.lens = d_lens.as<int32_t>(); a.scale = d_scale.as<double>();
+    a.x = d_xt; a.dtype = dtype; a.variant = variant; a.B = B; a.N = N; a.in_rows = rows;
+    a.lens = d_lens; a.scale = d_scale;
     a.sps = sps; a.interp_half_len = half_len; a.alpha = alpha; a.mu0 = mu0;
     a.do_fll = fll ? 1 : 0; a.Bn = Bn; a.y = y;
     a.i0 = d_i0.as<double>(); a.fll_state_in = d_stin.as<double>(); a.fll_state_out = d_stout.as<double>();
@@ -455,6 +431,229 @@ static int run_host(dsp_ctx *c, const void *x, int dtype, int64_t B, int64_t N, 
         if (status[(size_t)b] & 1)
             return fail(DSP_E_CAPACITY, "burst %lld: out_stride %lld too small (loop still running "
                         "after %d symbols)", (long long)b, (long long)out_stride, nout_h[b]);
+    return DSP_OK;
+}
+
+static int run_host(dsp_ctx *c, const void *x, int dtype, int64_t B, int64_t N, int64_t x_stride,
+                    const int32_t *lens, const double *scale, int sps, double alpha, double mu0,
+                    int variant, int half_len, bool fll, double Bn, double y, const double *i0,
+                    const double *st_in, double *st_out, void *rec, void *err, void *mu, void *sig,
+                    void *freq, void *ef, uint8_t *dec, int32_t *n_out, int64_t out_stride)
+{
+    if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    if (B < 0 || N < 0) return fail(DSP_E_ARG, "negative B or N");
+    if (B == 0) return DSP_OK;
+    if (!x) return fail(DSP_E_ARG, "x is NULL");
+    if (dtype != DSP_C64 && dtype != DSP_C128) return fail(DSP_E_ARG, "bad dtype");
+    if (x_stride < N) return fail(DSP_E_ARG, "x_stride < N");
+    if (out_stride < 1) return fail(DSP_E_ARG, "out_stride < 1");
+    if (lens)
+        for (int64_t b = 0; b < B; b++)
+            if (lens[b] < 0 || lens[b] > N) return fail(DSP_E_ARG, "lens[%lld] out of range", (long long)b);
+    HIP_TRY(hipSetDevice(c->device));
+    const int ce = dtype == DSP_C128 ? 16 : 8;
+    const int64_t rows = dsp_tile_rows(N);
+    const int64_t ntiles = (B + 63) / 64;
+    hipStream_t s = c->stream;
+    DevBuf d_x, d_xt, d_lens, d_scale;
+    HIP_TRY(d_x.alloc((size_t)B * x_stride * ce));
+    HIP_TRY(d_xt.alloc((size_t)ntiles * rows * 64 * ce));
+    HIP_TRY(hipMemcpyAsync(d_x.p, x, (size_t)B * x_stride * ce, hipMemcpyHostToDevice, s));
+    if (lens) {
+        HIP_TRY(d_lens.alloc((size_t)B * 4));
+        HIP_TRY(hipMemcpyAsync(d_lens.p, lens, (size_t)B * 4, hipMemcpyHostToDevice, s));
+    }
+    if (scale) {
+        HIP_TRY(d_scale.alloc((size_t)B * 8));
+        HIP_TRY(hipMemcpyAsync(d_scale.p, scale, (size_t)B * 8, hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(launch_tile_from_bursts(d_x.p, x_stride, d_lens.as<int>(), (int)N, (int)B, d_xt.p, (int)rows,
+                                    ce, s));
+    return sync_to_host(c, d_xt.p, dtype, B, N, rows, d_lens.as<int32_t>(), d_scale.as<double>(), sps,
+                        alpha, mu0, variant, half_len, fll, Bn, y, i0, st_in, st_out, rec, err, mu, sig,
+                        freq, ef, dec, n_out, out_stride);
+}
+
+// ---------------------------------------------------------------------------
+// FIR / loaders
+static int in_elem_bytes(int in_kind) { return in_kind == DSP_C128 ? 16 : (in_kind == DSP_I16 ? 4 : 8); }
+
+int64_t dsp_fir_workspace_bytes(int in_kind, int64_t B, int64_t N, int n_taps)
+{
+    FirParams P;
+    if (n_taps < 1 || !fir_plan(in_kind, n_taps, (int)N, P)) return 0;
+    return (int64_t)B * P.nchunk * 4 * 8;
+}
+
+int dsp_fir_tiles_dev(dsp_ctx *c, const dsp_fir_args *a)
+{
+    if (!c || !a) return fail(DSP_E_ARG, "ctx/args is NULL");
+    if (a->B <= 0) return DSP_OK;
+    if (!a->src || !a->h || a->n_taps < 1) return fail(DSP_E_ARG, "fir: NULL src/h or no taps");
+    if (a->in_kind < 0 || a->in_kind > 2) return fail(DSP_E_ARG, "fir: bad in_kind");
+    if (a->N < 0 || a->N >= (1LL << 30)) return fail(DSP_E_ARG, "fir: N out of range");
+    if (a->tiles && a->rows < a->N) return fail(DSP_E_ARG, "fir: rows < N");
+    FirParams P;
+    memset(&P, 0, sizeof(P));
+    if (!fir_plan(a->in_kind, a->n_taps, (int)a->N, P))
+        return fail(DSP_E_ARG, "fir: %d taps are too many for the LDS-tiled kernel", a->n_taps);
+    const bool want_std = a->std_out || a->inv_std_out;
+    if (want_std && (!a->workspace || a->workspace_bytes < (int64_t)a->B * P.nchunk * 32))
+        return fail(DSP_E_ARG, "fir: workspace too small (need %lld bytes)", (long long)a->B * P.nchunk * 32);
+    P.src = a->src; P.ld = a->src_stride; P.lens = a->lens; P.len_all = (int)a->N; P.B = (int)a->B;
+    P.h = a->h; P.M = a->n_taps; P.start = a->start < 0 ? (a->n_taps - 1) / 2 : a->start;
+    P.in_scale = a->in_scale; P.dst = a->tiles; P.rows = (int)a->rows; P.scale = a->scale;
+    P.stats = want_std ? (double *)a->workspace : nullptr;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_fir_tile(P, a->in_kind, c->stream));
+    if (want_std)
+        HIP_TRY(launch_fir_stats_finish(P.stats, P.nchunk, P.B, a->std_out, a->inv_std_out, c->stream));
+    return DSP_OK;
+}
+
+int dsp_load_iq_i16(dsp_ctx *c, const int16_t *iq, int64_t n_words, int normalize, float *out_c64,
+                    int64_t *n_out)
+{
+    if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    if (n_words < 2) return fail(DSP_E_ARG, "load_iq_i16: need at least one I/Q pair");   // :80-81
+    if (!iq || !out_c64) return fail(DSP_E_ARG, "load_iq_i16: NULL buffer");
+    const int64_t n = n_words / 2;                                                     // :82-83
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf d_raw, d_out, d_tmp;
+    HIP_TRY(d_raw.alloc((size_t)n * 4));
+    HIP_TRY(d_out.alloc((size_t)n * 8));
+    HIP_TRY(d_tmp.alloc(16));
+    HIP_TRY(hipMemcpyAsync(d_raw.p, iq, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_iq_i16(d_raw.p, n, normalize, d_tmp.as<unsigned>(), d_tmp.as<float>() + 1, d_out.p, c->stream));
+    HIP_TRY(hipMemcpyAsync(out_c64, d_out.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (n_out) *n_out = n;
+    return DSP_OK;
+}
+
+int dsp_load_iq_f32(dsp_ctx *c, const float *iq, int64_t n_words, float *out_c64, int64_t *n_out)
+{
+    (void)c;
+    if (n_words < 0 || (n_words && (!iq || !out_c64))) return fail(DSP_E_ARG, "load_iq_f32: bad arguments");
+    const int64_t n = n_words / 2;
+    if (n) memcpy(out_c64, iq, (size_t)n * 8);      // interleaved float32 I,Q already is complex64
+    if (n_out) *n_out = n;
+    return DSP_OK;
+}
+
+// FIR of burst-major host bursts -> device tiles (+ stats).  Shared by dsp_fir_same_std and
+// dsp_rx_chain.  On return d_tiles holds the (optionally scaled) filter output.
+struct FirStage {
+    DevBuf d_x, d_lens, d_h, d_tiles, d_ws, d_std, d_inv, d_peak;
+    int64_t rows = 0;
+};
+
+static int fir_stage(dsp_ctx *c, FirStage &S, const void *x, int in_kind, int64_t B, int64_t N,
+                     int64_t x_stride, const int32_t *lens, int normalize_peak, const double *h,
+                     int n_taps, int start, bool want_std, bool scaled_output)
+{
+    const int ie = in_elem_bytes(in_kind), oe = in_kind == DSP_C128 ? 16 : 8;
+    hipStream_t s = c->stream;
+    S.rows = dsp_tile_rows(N);
+    const int64_t ntiles = (B + 63) / 64;
+    HIP_TRY(S.d_x.alloc((size_t)B * x_stride * ie));
+    HIP_TRY(hipMemcpyAsync(S.d_x.p, x, (size_t)B * x_stride * ie, hipMemcpyHostToDevice, s));
+    if (lens) {
+        HIP_TRY(S.d_lens.alloc((size_t)B * 4));
+        HIP_TRY(hipMemcpyAsync(S.d_lens.p, lens, (size_t)B * 4, hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(S.d_h.alloc((size_t)n_taps * 8));
+    HIP_TRY(hipMemcpyAsync(S.d_h.p, h, (size_t)n_taps * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(S.d_tiles.alloc((size_t)ntiles * S.rows * 64 * oe));
+    HIP_TRY(hipMemsetAsync(S.d_tiles.p, 0, (size_t)ntiles * S.rows * 64 * oe, s));
+    HIP_TRY(S.d_std.alloc((size_t)B * 8));
+    HIP_TRY(S.d_inv.alloc((size_t)B * 8));
+    HIP_TRY(S.d_peak.alloc(16));
+    const float *in_scale = nullptr;
+    if (in_kind == DSP_I16) {
+        // one peak over the whole [B][x_stride] block (a capture cut into bursts shares its peak)
+        HIP_TRY(launch_iq_i16(S.d_x.p, B * x_stride, normalize_peak, S.d_peak.as<unsigned>(),
+                              S.d_peak.as<float>() + 1, nullptr, s));
+        in_scale = S.d_peak.as<float>() + 1;
+    }
+    FirParams probe;
+    if (!fir_plan(in_kind, n_taps, (int)N, probe)) {
+        // long filter: direct form into a complex128 burst-major buffer, exact two-pass std,
+        // scale in float64, then one rounding into the tiles
+        DevBuf d_y64, d_y32;
+        HIP_TRY(d_y64.alloc((size_t)B * N * 16));
+        HIP_TRY(hipMemsetAsync(d_y64.p, 0, (size_t)B * N * 16, s));
+        FirParams P;
+        memset(&P, 0, sizeof(P));
+        P.src = S.d_x.p; P.ld = x_stride; P.lens = S.d_lens.as<int>(); P.len_all = (int)N; P.B = (int)B;
+        P.h = S.d_h.as<double>(); P.M = n_taps; P.start = start < 0 ? (n_taps - 1) / 2 : start;
+        P.in_scale = in_scale;
+        HIP_TRY(launch_fir_direct(P, in_kind, d_y64.p, N, (int)N, s));
+        if (want_std)
+            HIP_TRY(launch_burst_std(d_y64.p, 1, N, S.d_lens.as<int>(), (int)N, (int)B,
+                                     S.d_std.as<double>(), S.d_inv.as<double>(), s));
+        if (want_std && scaled_output)
+            HIP_TRY(launch_burst_scale(d_y64.p, 1, N, S.d_lens.as<int>(), (int)N, (int)B, (int)N,
+                                       S.d_inv.as<double>(), s));
+        if (oe == 16) {
+            HIP_TRY(launch_tile_from_bursts(d_y64.p, N, S.d_lens.as<int>(), (int)N, (int)B, S.d_tiles.p,
+                                            (int)S.rows, 16, s));
+        } else {
+            HIP_TRY(d_y32.alloc((size_t)B * N * 8));
+            HIP_TRY(launch_burst_cast(d_y64.p, N, d_y32.p, N, (int)B, (int)N, s));
+            HIP_TRY(launch_tile_from_bursts(d_y32.p, N, S.d_lens.as<int>(), (int)N, (int)B, S.d_tiles.p,
+                                            (int)S.rows, 8, s));
+        }
+        HIP_TRY(hipStreamSynchronize(s));      // the temporaries die with this scope
+        return DSP_OK;
+    }
+    dsp_fir_args a;
+    memset(&a, 0, sizeof(a));
+    a.src = S.d_x.p; a.in_kind = in_kind; a.start = start; a.B = B; a.N = N; a.src_stride = x_stride;
+    a.lens = S.d_lens.as<int32_t>(); a.h = S.d_h.as<double>(); a.n_taps = n_taps; a.in_scale = in_scale;
+    a.rows = S.rows;
+    int64_t wsb = dsp_fir_workspace_bytes(in_kind, B, N, n_taps);
+    HIP_TRY(S.d_ws.alloc((size_t)(wsb > 0 ? wsb : 16)));
+    a.workspace = S.d_ws.p; a.workspace_bytes = wsb;
+    if (want_std && scaled_output) {
+        // pass 1: statistics only; pass 2: filter again, multiply by 1/std, round once
+        a.tiles = nullptr; a.std_out = S.d_std.as<double>(); a.inv_std_out = S.d_inv.as<double>();
+        int rc = dsp_fir_tiles_dev(c, &a);
+        if (rc != DSP_OK) return rc;
+        a.tiles = S.d_tiles.p; a.std_out = nullptr; a.inv_std_out = nullptr; a.scale = S.d_inv.as<double>();
+        return dsp_fir_tiles_dev(c, &a);
+    }
+    a.tiles = S.d_tiles.p;
+    if (want_std) { a.std_out = S.d_std.as<double>(); a.inv_std_out = S.d_inv.as<double>(); }
+    return dsp_fir_tiles_dev(c, &a);
+}
+
+int dsp_fir_same_std(dsp_ctx *c, const void *x, int dtype, int64_t B, int64_t N, int64_t x_stride,
+                     const int32_t *lens, const double *h, int n_taps, int start, int normalize_std,
+                     void *y, int64_t y_stride, double *std_out)
+{
+    if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    if (B < 0 || N < 0) return fail(DSP_E_ARG, "negative B or N");
+    if (B == 0 || N == 0) return DSP_OK;
+    if (!x || !y || !h || n_taps < 1) return fail(DSP_E_ARG, "fir: NULL argument");
+    if (dtype != DSP_C64 && dtype != DSP_C128) return fail(DSP_E_ARG, "fir: bad dtype");
+    if (x_stride < N || y_stride < N) return fail(DSP_E_ARG, "fir: stride < N");
+    if (n_taps > N) return fail(DSP_E_ARG, "fir: n_taps > N (np.convolve would swap its operands)");
+    HIP_TRY(hipSetDevice(c->device));
+    const int oe = dtype == DSP_C128 ? 16 : 8;
+    hipStream_t s = c->stream;
+    const bool want_std = normalize_std || std_out;
+    DevBuf d_y;
+    HIP_TRY(d_y.alloc((size_t)B * y_stride * oe));
+    FirStage S;
+    int rc = fir_stage(c, S, x, dtype, B, N, x_stride, lens, 0, h, n_taps, start, want_std,
+                       normalize_std != 0);
+    if (rc != DSP_OK) return rc;
+    HIP_TRY(hipMemsetAsync(d_y.p, 0, (size_t)B * y_stride * oe, s));
+    HIP_TRY(launch_bursts_from_tiles(S.d_tiles.p, (int)S.rows, (int)B, d_y.p, y_stride, (int)N, oe, s));
+    HIP_TRY(hipMemcpyAsync(y, d_y.p, (size_t)B * y_stride * oe, hipMemcpyDeviceToHost, s));
+    if (std_out) HIP_TRY(hipMemcpyAsync(std_out, S.d_std.p, (size_t)B * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     return DSP_OK;
 }
 
@@ -491,6 +690,39 @@ int dsp_sync_chain(dsp_ctx *c, const void *x, int dtype, int64_t B, int64_t N, i
     return run_host(c, x, dtype, B, N, x_stride, lens, scale, sps, alpha, mu0, variant,
                     interp_half_len, true, Bn, y, nullptr, nullptr, nullptr, rec, err, mu, sig, freq,
                     ef, dec, n_out, out_stride);
+}
+
+int dsp_rx_chain(dsp_ctx *c, const void *x, int in_kind, int64_t B, int64_t N, int64_t x_stride,
+                 const int32_t *lens, int normalize_peak, const double *h, int n_taps,
+                 int normalize_std, int sps, double alpha, double mu0, int variant,
+                 int interp_half_len, double Bn, double y,
+                 void *rec, void *err, void *mu, void *sig, void *freq, void *ef, uint8_t *dec,
+                 int32_t *n_out, int64_t out_stride, double *std_out)
+{
+    if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    if (B < 0 || N < 0) return fail(DSP_E_ARG, "negative B or N");
+    if (B == 0) return DSP_OK;
+    if (!x || !h || n_taps < 1) return fail(DSP_E_ARG, "rx_chain: NULL argument");
+    if (in_kind < 0 || in_kind > 2) return fail(DSP_E_ARG, "rx_chain: bad in_kind");
+    if (variant != DSP_GARDNER2 && variant != DSP_GARDNER_TED) return fail(DSP_E_ARG, "rx_chain: bad variant");
+    if (sps < 1) return fail(DSP_E_ARG, "rx_chain: sps must be >= 1");
+    if (x_stride < N) return fail(DSP_E_ARG, "rx_chain: x_stride < N");
+    if (n_taps > N) return fail(DSP_E_ARG, "rx_chain: n_taps > N");
+    if (lens)
+        for (int64_t b = 0; b < B; b++)
+            if (lens[b] < 0 || lens[b] > N) return fail(DSP_E_ARG, "lens[%lld] out of range", (long long)b);
+    HIP_TRY(hipSetDevice(c->device));
+    FirStage S;
+    const bool want_std = normalize_std || std_out;
+    int rc = fir_stage(c, S, x, in_kind, B, N, x_stride, lens, normalize_peak, h, n_taps, -1, want_std,
+                       false);
+    if (rc != DSP_OK) return rc;
+    if (std_out) HIP_TRY(hipMemcpyAsync(std_out, S.d_std.p, (size_t)B * 8, hipMemcpyDeviceToHost, c->stream));
+    const int dtype = in_kind == DSP_C128 ? DSP_C128 : DSP_C64;
+    return sync_to_host(c, S.d_tiles.p, dtype, B, N, S.rows, S.d_lens.as<int32_t>(),
+                        normalize_std ? S.d_inv.as<double>() : nullptr, sps, alpha, mu0, variant,
+                        interp_half_len, true, Bn, y, nullptr, nullptr, nullptr, rec, err, mu, sig, freq,
+                        ef, dec, n_out, out_stride);
 }
 
 }  // extern "C"

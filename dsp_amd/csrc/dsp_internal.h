@@ -55,3 +55,35 @@ hipError_t launch_tile_from_bursts(const void *src, int64_t ld, const int *lens,
                                    void *dst, int rows, int elem_bytes, hipStream_t stream);
 hipError_t launch_bursts_from_tiles(const void *src, int rows, int B, void *dst, int64_t ld,
                                     int ncopy, int elem_bytes, hipStream_t stream);
+
+// ---------------------------------------------------------------------------
+// FIR / loaders (fir_kernels.hip)
+enum { DSP_IN_C64 = 0, DSP_IN_C128 = 1, DSP_IN_I16 = 2 };
+
+struct FirParams {
+    const void *src;          // burst-major [B][ld] samples: int16 pairs, complex64 or complex128
+    int64_t ld;               // samples between consecutive bursts (may be < N: overlapping views)
+    const int *lens;          // [B] or NULL -> len_all
+    int len_all, B;
+    const double *h;          // device taps [M]
+    int M, start;             // y[n] = sum_j h[j] x[n + start - j]
+    const float *in_scale;    // device scalar applied to int16 samples in float32, or NULL
+    void *dst;                // tiles [ntiles][rows][64] (complex64 / complex128), or NULL: stats only
+    int rows;
+    const double *scale;      // [B] factor applied to the outputs (1/std), or NULL
+    double *stats;            // [B][nchunk][4] partial statistics, or NULL
+    int nchunk, CH, W, stride;
+};
+
+bool fir_plan(int in_kind, int M, int n_out, FirParams &P);
+hipError_t launch_fir_tile(const FirParams &P, int in_kind, hipStream_t s);
+hipError_t launch_fir_stats_finish(const double *stats, int nchunk, int B, double *std_out, double *inv_out,
+                                   hipStream_t s);
+hipError_t launch_fir_direct(const FirParams &P, int in_kind, void *dst, int64_t dst_ld, int n_out, hipStream_t s);
+hipError_t launch_burst_std(const void *y, int c128, int64_t ld, const int *lens, int len_all, int B,
+                            double *std_out, double *inv_out, hipStream_t s);
+hipError_t launch_burst_scale(void *y, int c128, int64_t ld, const int *lens, int len_all, int B, int n_max,
+                              const double *scale, hipStream_t s);
+hipError_t launch_burst_cast(const void *src, int64_t src_ld, void *dst, int64_t dst_ld, int B, int n, hipStream_t s);
+hipError_t launch_iq_i16(const void *raw, int64_t n, int normalize, unsigned *peak2, float *iscale, void *out,
+                         hipStream_t s);

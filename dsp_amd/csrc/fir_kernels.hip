@@ -1,0 +1,395 @@
+// fir_kernels.hip -- matched filter (real taps x complex samples, 'same' /
+// cropped full convolution), np.std normalisation, and the raw IQ loaders.
+//
+//   y[n] = sum_j h[j] x[n + start - j]     np.convolve(x, h, 'same'): start = (M-1)//2
+//                                           (worker.py:176); apply_filter: start = M//2
+//                                           (hw1/test_rrc_cascade.py:103-108)
+//   y / np.std(y)                           worker.py:177 (population std of a complex vector)
+//
+// fir_tile_kernel: one workgroup = one tile (64 bursts) x CH output samples.
+// The input window of every burst is staged in LDS with coalesced loads along
+// the burst (complex64 HBM loads, int16 pairs or complex128), taps are read
+// from LDS as broadcasts, each lane (= burst) then slides an OG-output register
+// block over the taps in float64.  Outputs leave as full 64-lane rows of the
+// tiled layout (lane = burst), so no output transpose is needed.  Per (burst,
+// chunk) partial statistics (count, mean, M2) are merged by fir_stats_finish
+// with Chan's formula -> 1/std per burst, applied by the consumer kernels.
+#include "dsp_internal.h"
+
+namespace {
+
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef double d2v __attribute__((ext_vector_type(2)));
+typedef short s2v __attribute__((ext_vector_type(2)));
+
+template <typename IN> struct Stage;                     // LDS staging type of an input type
+template <> struct Stage<s2v> { typedef f2v T; };
+template <> struct Stage<f2v> { typedef f2v T; };
+template <> struct Stage<d2v> { typedef d2v T; };
+
+__device__ __forceinline__ f2v to_stage(s2v v, float isc) { return f2v{(float)v.x * isc, (float)v.y * isc}; }
+__device__ __forceinline__ f2v to_stage(f2v v, float) { return v; }
+__device__ __forceinline__ d2v to_stage(d2v v, float) { return v; }
+
+__device__ __forceinline__ void put(f2v *p, double re, double im) { *p = f2v{(float)re, (float)im}; }
+__device__ __forceinline__ void put(d2v *p, double re, double im) { *p = d2v{re, im}; }
+
+template <typename IN, typename OUT, int OG>
+__global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
+{
+    typedef typename Stage<IN>::T ST;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int M = P.M, CH = P.CH, W = P.W, stride = P.stride;
+    double *hrev = (double *)smem;                                  // [M] reversed taps
+    ST *xs = (ST *)(smem + (((size_t)M * 8 + 15) & ~(size_t)15));  // [64][stride]
+    double *red = (double *)xs;                                     // [4][64][4] reduction scratch, reuses xs
+
+    const int tile = blockIdx.y, chunk = blockIdx.x;
+    const int n0 = chunk * CH;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float isc = P.in_scale ? *P.in_scale : 1.0f;
+
+    for (int i = threadIdx.x; i < M; i += 256) hrev[i] = P.h[M - 1 - i];
+    // stage the input windows: xs[bb][i] = x[b][n0 + start - (M-1) + i], zero outside the burst
+    const int x0 = n0 + P.start - (M - 1);
+    for (int q = 0; q < 16; q++) {
+        const int bb = w * 16 + q;
+        const int b = tile * 64 + bb;
+        const int len = b < P.B ? (P.lens ? P.lens[b] : P.len_all) : 0;
+        const IN *src = (const IN *)P.src + (int64_t)b * P.ld;
+        for (int i = lane; i < W; i += 64) {
+            const int n = x0 + i;
+            ST v = ST{0, 0};
+            if (n >= 0 && n < len) v = to_stage(src[n], isc);
+            xs[(size_t)bb * stride + i] = v;
+        }
+    }
+    __syncthreads();
+
+    // lane = burst; this wave computes outputs [w*CH/4, (w+1)*CH/4) of the chunk, OG at a time
+    const int b = tile * 64 + lane;
+    const int len = b < P.B ? (P.lens ? P.lens[b] : P.len_all) : 0;
+    const double scale = (P.scale && b < P.B) ? P.scale[b] : 1.0;
+    const ST *xrow = xs + (size_t)lane * stride;
+    OUT *dst = P.dst ? (OUT *)P.dst + (size_t)tile * P.rows * 64 + lane : nullptr;
+    const int per_wave = CH / 4;
+    double s_re = 0.0, s_im = 0.0;      // sums of this lane's valid outputs
+    int cnt = 0;
+    // keep the outputs for the second (M2) pass in registers: per_wave <= 32
+    double yre[32], yim[32];
+#pragma unroll
+    for (int g = 0; g < 32 / OG; g++) {
+        if (g * OG < per_wave) {
+            const int o0 = w * per_wave + g * OG;
+            double are[OG], aim[OG];
+#pragma unroll
+            for (int o = 0; o < OG; o++) { are[o] = 0.0; aim[o] = 0.0; }
+            for (int i0 = 0; i0 < M; i0 += 8) {
+                ST xw[OG + 7];
+#pragma unroll
+                for (int j = 0; j < OG + 7; j++) xw[j] = xrow[o0 + i0 + j];
+#pragma unroll
+                for (int ii = 0; ii < 8; ii++) {
+                    const double hv = (i0 + ii < M) ? hrev[i0 + ii] : 0.0;
+#pragma unroll
+                    for (int o = 0; o < OG; o++) {
+                        are[o] = __builtin_fma(hv, (double)xw[o + ii].x, are[o]);
+                        aim[o] = __builtin_fma(hv, (double)xw[o + ii].y, aim[o]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < OG; o++) {
+                const int n = n0 + o0 + o;
+                const bool valid = n < len;
+                yre[g * OG + o] = valid ? are[o] : 0.0;
+                yim[g * OG + o] = valid ? aim[o] : 0.0;
+                if (valid) { s_re += are[o]; s_im += aim[o]; cnt++; }
+                if (dst && n < P.rows) put(dst + (size_t)n * 64, valid ? are[o] * scale : 0.0,
+                                           valid ? aim[o] * scale : 0.0);
+            }
+        }
+    }
+    if (!P.stats) return;
+    // ---- per (burst, chunk) statistics: exact two-pass inside the chunk ----------
+    __syncthreads();                    // every wave is done with xs: reuse it as scratch
+    red[(w * 64 + lane) * 4 + 0] = s_re;
+    red[(w * 64 + lane) * 4 + 1] = s_im;
+    red[(w * 64 + lane) * 4 + 2] = (double)cnt;
+    __syncthreads();
+    double t_re = 0.0, t_im = 0.0, t_n = 0.0;
+    for (int q = 0; q < 4; q++) {
+        t_re += red[(q * 64 + lane) * 4 + 0];
+        t_im += red[(q * 64 + lane) * 4 + 1];
+        t_n += red[(q * 64 + lane) * 4 + 2];
+    }
+    const double m_re = t_n > 0.0 ? t_re / t_n : 0.0, m_im = t_n > 0.0 ? t_im / t_n : 0.0;
+    double m2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        if (j < per_wave) {
+            const int n = n0 + w * per_wave + j;
+            if (n < len) {
+                const double dr = yre[j] - m_re, di = yim[j] - m_im;
+                m2 += dr * dr + di * di;
+            }
+        }
+    }
+    __syncthreads();
+    red[(w * 64 + lane) * 4 + 3] = m2;
+    __syncthreads();
+    if (w == 0 && b < P.B) {
+        double t_m2 = 0.0;
+        for (int q = 0; q < 4; q++) t_m2 += red[(q * 64 + lane) * 4 + 3];
+        double *st = P.stats + ((size_t)b * P.nchunk + chunk) * 4;
+        st[0] = t_n; st[1] = m_re; st[2] = m_im; st[3] = t_m2;
+    }
+}
+
+// merge the chunk statistics of each burst (Chan et al.) -> std and 1/std
+__global__ void fir_stats_finish(const double *__restrict__ stats, int nchunk, int B,
+                                 double *__restrict__ std_out, double *__restrict__ inv_out)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double n = 0.0, mr = 0.0, mi = 0.0, m2 = 0.0;
+    for (int c = 0; c < nchunk; c++) {
+        const double *s = stats + ((size_t)b * nchunk + c) * 4;
+        const double nb = s[0];
+        if (nb <= 0.0) continue;
+        const double nn = n + nb;
+        const double dr = s[1] - mr, di = s[2] - mi;
+        m2 += s[3] + (dr * dr + di * di) * (n * nb / nn);
+        mr += dr * (nb / nn);
+        mi += di * (nb / nn);
+        n = nn;
+    }
+    const double sd = n > 0.0 ? sqrt(m2 / n) : __builtin_nan("");
+    if (std_out) std_out[b] = sd;
+    if (inv_out) inv_out[b] = 1.0 / sd;          // numpy: complex / real scalar = * (1/std)
+}
+
+// generic fallback for long filters: one thread per output sample, burst-major in and out
+template <typename IN, typename OUT>
+__global__ void fir_direct_kernel(FirParams P, OUT *__restrict__ dst, int64_t dst_ld)
+{
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int len = P.lens ? P.lens[b] : P.len_all;
+    if (n >= len) return;
+    const IN *src = (const IN *)P.src + (int64_t)b * P.ld;
+    const float isc = P.in_scale ? *P.in_scale : 1.0f;
+    const int m = n + P.start;
+    int j_hi = m < P.M - 1 ? m : P.M - 1;
+    int j_lo = m - (len - 1) > 0 ? m - (len - 1) : 0;
+    double sr = 0.0, si = 0.0;
+    for (int j = j_hi; j >= j_lo; j--) {
+        auto v = to_stage(src[m - j], isc);
+        sr = __builtin_fma(P.h[j], (double)v.x, sr);
+        si = __builtin_fma(P.h[j], (double)v.y, si);
+    }
+    const double scale = P.scale ? P.scale[b] : 1.0;
+    put(dst + (int64_t)b * dst_ld + n, sr * scale, si * scale);
+}
+
+// exact two-pass np.std of burst-major complex rows (one workgroup per burst)
+template <typename T>
+__global__ __launch_bounds__(256) void burst_std_kernel(const T *__restrict__ y, int64_t ld, const int *lens,
+                                                       int len_all, double *__restrict__ std_out,
+                                                       double *__restrict__ inv_out)
+{
+    __shared__ double red[256 * 2];
+    const int b = blockIdx.x;
+    const int len = lens ? lens[b] : len_all;
+    const T *row = y + (int64_t)b * ld;
+    double sr = 0.0, si = 0.0;
+    for (int i = threadIdx.x; i < len; i += 256) { sr += (double)row[i].x; si += (double)row[i].y; }
+    red[threadIdx.x * 2] = sr; red[threadIdx.x * 2 + 1] = si;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { red[threadIdx.x * 2] += red[(threadIdx.x + s) * 2]; red[threadIdx.x * 2 + 1] += red[(threadIdx.x + s) * 2 + 1]; }
+        __syncthreads();
+    }
+    const double mr = red[0] / (double)len, mi = red[1] / (double)len;
+    __syncthreads();
+    double m2 = 0.0;
+    for (int i = threadIdx.x; i < len; i += 256) {
+        const double dr = (double)row[i].x - mr, di = (double)row[i].y - mi;
+        m2 += dr * dr + di * di;
+    }
+    red[threadIdx.x] = m2;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double sd = len > 0 ? sqrt(red[0] / (double)len) : __builtin_nan("");
+        if (std_out) std_out[b] = sd;
+        if (inv_out) inv_out[b] = 1.0 / sd;
+    }
+}
+
+// y *= scale[b] on burst-major rows (complex128: y * (1/std) exactly as numpy divides)
+template <typename T>
+__global__ void burst_scale_kernel(T *__restrict__ y, int64_t ld, const int *lens, int len_all,
+                                   const double *__restrict__ scale)
+{
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int len = lens ? lens[b] : len_all;
+    if (n >= len) return;
+    T v = y[(int64_t)b * ld + n];
+    const double s = scale[b];
+    put(&y[(int64_t)b * ld + n], (double)v.x * s, (double)v.y * s);
+}
+
+// complex128 -> complex64 rows (one rounding)
+__global__ void burst_cast_kernel(const d2v *__restrict__ src, int64_t src_ld, f2v *__restrict__ dst, int64_t dst_ld,
+                                  int n)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const d2v v = src[(int64_t)b * src_ld + i];
+    dst[(int64_t)b * dst_ld + i] = f2v{(float)v.x, (float)v.y};
+}
+
+// ---- raw IQ loaders (hw1/gardner.py:77-91) -----------------------------------
+// peak^2 = max(i^2 + q^2) over the capture, exact in integers
+__global__ void iq_i16_peak_kernel(const s2v *__restrict__ raw, int64_t n, unsigned *__restrict__ peak2)
+{
+    unsigned m = 0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int a = raw[i].x, c = raw[i].y;
+        const unsigned v = (unsigned)(a * a) + (unsigned)(c * c);
+        m = v > m ? v : m;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o = __shfl_down(m, off);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(peak2, m);
+}
+
+// 1/peak in float32, as numpy's complex64 / float32 scalar computes it:
+// peak = float32(hypot) (exact sqrt of the integer in double, rounded once), scl = 1.0f / peak
+__global__ void iq_i16_scale_kernel(const unsigned *__restrict__ peak2, int normalize, float *__restrict__ iscale)
+{
+    float s = 1.0f;
+    if (normalize && *peak2 > 0) {
+        const float peak = (float)sqrt((double)*peak2);
+        s = 1.0f / peak;
+    }
+    *iscale = s;
+}
+
+__global__ void iq_i16_convert_kernel(const s2v *__restrict__ raw, int64_t n, const float *__restrict__ iscale,
+                                      f2v *__restrict__ out)
+{
+    const float s = *iscale;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = f2v{(float)raw[i].x * s, (float)raw[i].y * s};
+}
+
+template <typename IN, typename OUT, int OG>
+hipError_t launch_fir_tile_t(const FirParams &P, hipStream_t s)
+{
+    const int nchunk = P.nchunk, ntiles = (P.B + 63) / 64;
+    size_t xs_bytes = (size_t)64 * P.stride * sizeof(typename Stage<IN>::T);
+    if (xs_bytes < (size_t)4 * 64 * 4 * 8) xs_bytes = (size_t)4 * 64 * 4 * 8;
+    size_t lds = (((size_t)P.M * 8 + 15) & ~(size_t)15) + xs_bytes;
+    hipLaunchKernelGGL((fir_tile_kernel<IN, OUT, OG>), dim3(nchunk, ntiles), dim3(256), lds, s, P);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// choose the chunk geometry; returns false if the filter is too long for the LDS-tiled kernel
+bool fir_plan(int in_kind, int M, int n_out, FirParams &P)
+{
+    const int elem = in_kind == DSP_IN_C128 ? 16 : 8;
+    const int og = in_kind == DSP_IN_C128 ? 4 : 8;
+    if (M > 4096) return false;
+    const size_t budget = 64 * 1024 - (((size_t)M * 8 + 15) & ~(size_t)15);
+    const int m8 = (M + 7) & ~7;
+    int best = 0;
+    for (int CH = 128; CH >= 4 * og; CH -= 4 * og) {
+        int W = CH + m8 - 1;               // highest staged index read: CH + ceil8(M) - 2
+        int stride = W | 1;
+        if ((size_t)64 * stride * elem <= budget) { best = CH; break; }
+    }
+    if (!best) return false;
+    P.CH = best; P.W = best + m8 - 1; P.stride = P.W | 1;
+    P.nchunk = (n_out + best - 1) / best;
+    return true;
+}
+
+hipError_t launch_fir_tile(const FirParams &P, int in_kind, hipStream_t s)
+{
+    switch (in_kind) {
+        case DSP_IN_I16: return launch_fir_tile_t<s2v, f2v, 8>(P, s);
+        case DSP_IN_C64: return launch_fir_tile_t<f2v, f2v, 8>(P, s);
+        case DSP_IN_C128: return launch_fir_tile_t<d2v, d2v, 4>(P, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_fir_stats_finish(const double *stats, int nchunk, int B, double *std_out, double *inv_out,
+                                   hipStream_t s)
+{
+    hipLaunchKernelGGL(fir_stats_finish, dim3((B + 255) / 256), dim3(256), 0, s, stats, nchunk, B, std_out, inv_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_fir_direct(const FirParams &P, int in_kind, void *dst, int64_t dst_ld, int n_out, hipStream_t s)
+{
+    dim3 grid((n_out + 255) / 256, P.B), block(256);
+    switch (in_kind) {
+        // the direct form always writes complex128 (statistics and scaling stay in float64)
+        case DSP_IN_I16: hipLaunchKernelGGL((fir_direct_kernel<s2v, d2v>), grid, block, 0, s, P, (d2v *)dst, dst_ld); break;
+        case DSP_IN_C64: hipLaunchKernelGGL((fir_direct_kernel<f2v, d2v>), grid, block, 0, s, P, (d2v *)dst, dst_ld); break;
+        case DSP_IN_C128: hipLaunchKernelGGL((fir_direct_kernel<d2v, d2v>), grid, block, 0, s, P, (d2v *)dst, dst_ld); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_burst_std(const void *y, int c128, int64_t ld, const int *lens, int len_all, int B,
+                            double *std_out, double *inv_out, hipStream_t s)
+{
+    if (c128) hipLaunchKernelGGL(burst_std_kernel<d2v>, dim3(B), dim3(256), 0, s, (const d2v *)y, ld, lens, len_all, std_out, inv_out);
+    else hipLaunchKernelGGL(burst_std_kernel<f2v>, dim3(B), dim3(256), 0, s, (const f2v *)y, ld, lens, len_all, std_out, inv_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_burst_scale(void *y, int c128, int64_t ld, const int *lens, int len_all, int B, int n_max,
+                              const double *scale, hipStream_t s)
+{
+    dim3 grid((n_max + 255) / 256, B), block(256);
+    if (c128) hipLaunchKernelGGL(burst_scale_kernel<d2v>, grid, block, 0, s, (d2v *)y, ld, lens, len_all, scale);
+    else hipLaunchKernelGGL(burst_scale_kernel<f2v>, grid, block, 0, s, (f2v *)y, ld, lens, len_all, scale);
+    return hipGetLastError();
+}
+
+hipError_t launch_iq_i16(const void *raw, int64_t n, int normalize, unsigned *peak2, float *iscale, void *out,
+                         hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(peak2, 0, 4, s);
+    if (e != hipSuccess) return e;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    if (normalize) hipLaunchKernelGGL(iq_i16_peak_kernel, dim3(blocks), dim3(256), 0, s, (const s2v *)raw, n, peak2);
+    hipLaunchKernelGGL(iq_i16_scale_kernel, dim3(1), dim3(1), 0, s, peak2, normalize, iscale);
+    if (out) hipLaunchKernelGGL(iq_i16_convert_kernel, dim3(blocks), dim3(256), 0, s, (const s2v *)raw, n, iscale, (f2v *)out);
+    return hipGetLastError();
+}
+
+hipError_t launch_burst_cast(const void *src, int64_t src_ld, void *dst, int64_t dst_ld, int B, int n, hipStream_t s)
+{
+    if (B <= 0 || n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(burst_cast_kernel, dim3((n + 255) / 256, B), dim3(256), 0, s, (const d2v *)src, src_ld,
+                       (f2v *)dst, dst_ld, n);
+    return hipGetLastError();
+}

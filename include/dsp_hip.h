@@ -37,7 +37,7 @@ extern "C" {
 typedef struct dsp_ctx dsp_ctx;
 
 enum { DSP_OK = 0, DSP_E_ARG = -1, DSP_E_HIP = -2, DSP_E_CAPACITY = -3, DSP_E_NOMEM = -4 };
-enum { DSP_C64 = 0, DSP_C128 = 1 };
+enum { DSP_C64 = 0, DSP_C128 = 1, DSP_I16 = 2 /* interleaved int16 I,Q: loaders / dsp_rx_chain only */ };
 enum { DSP_GARDNER2 = 0,   /* gardner_timing_recovery, gardner2.py:6-100          */
        DSP_GARDNER_TED = 1 /* gardner_ted, hw1/gardner.py:22-74, read_file.py:53-104 */ };
 
@@ -105,6 +105,37 @@ int dsp_sync_chain(dsp_ctx *ctx, const void *x, int dtype, int64_t B, int64_t N,
                    void *rec, void *err, void *mu, void *sig, void *freq, void *ef, uint8_t *dec,
                    int32_t *n_out, int64_t out_stride);
 
+/* IQ PCM loaders (a8).  dsp_load_iq_i16: read_iq_int16(path, normalize) of
+ * hw1/gardner.py:77-91 on an in-memory word buffer: drops an odd trailing word,
+ * int16 -> float32 I,Q -> complex64, divides by max|iq| (float32 arithmetic, as
+ * numpy does for complex64) when normalize != 0 and the peak is > 0.  n_words < 2
+ * -> DSP_E_ARG (the reference raises ValueError).  dsp_load_iq_f32: the idiom
+ * s[::2] + 1j*s[1::2] of read_file.py:108-109 (no scaling; a host-side copy).   */
+int dsp_load_iq_i16(dsp_ctx *ctx, const int16_t *iq, int64_t n_words, int normalize, float *out_c64,
+                    int64_t *n_out);
+int dsp_load_iq_f32(dsp_ctx *ctx, const float *iq, int64_t n_words, float *out_c64, int64_t *n_out);
+
+/* Matched filter + normalisation (a2): y = convolve(x, h) cropped at `start`
+ * (start < 0: mode='same', i.e. (n_taps-1)/2 -- worker.py:176; n_taps/2 gives
+ * apply_filter of hw1/test_rrc_cascade.py:103-108), then y / np.std(y) per burst
+ * when normalize_std != 0 (worker.py:177).  float64 accumulation; y has the
+ * dtype of x.  std_out [B] (optional) receives np.std of the unnormalised y.   */
+int dsp_fir_same_std(dsp_ctx *ctx, const void *x, int dtype, int64_t B, int64_t N, int64_t x_stride,
+                     const int32_t *lens, const double *h, int n_taps, int start, int normalize_std,
+                     void *y, int64_t y_stride, double *std_out);
+
+/* The whole receive chain of worker.py:299-304 on raw bursts: [int16 peak
+ * normalisation ->] RRC 'same' -> / np.std -> Gardner -> fll_func -> decisions.
+ * in_kind DSP_I16 / DSP_C64: the matched-filter output is held as complex64 in
+ * HBM (float32 outputs); DSP_C128: everything float64.  The 1/std factor is
+ * folded into the recurrence kernel's loads.                                   */
+int dsp_rx_chain(dsp_ctx *ctx, const void *x, int in_kind, int64_t B, int64_t N, int64_t x_stride,
+                 const int32_t *lens, int normalize_peak, const double *h, int n_taps,
+                 int normalize_std, int sps, double alpha, double mu0, int variant,
+                 int interp_half_len, double Bn, double y,
+                 void *rec, void *err, void *mu, void *sig, void *freq, void *ef, uint8_t *dec,
+                 int32_t *n_out, int64_t out_stride, double *std_out);
+
 /* ---- device-resident tiled entry points ------------------------------------ */
 /* burst-major device array -> tiles (zero padded); rows = dsp_tile_rows(N).     */
 int dsp_tile_bursts_dev(dsp_ctx *ctx, const void *d_src, int dtype, int64_t B, int64_t N,
@@ -133,6 +164,29 @@ typedef struct dsp_sync_args {
     int32_t *n_out;         /* [B] or NULL                                           */
     int32_t *status;        /* [B] or NULL; bit0 = capacity reached                  */
 } dsp_sync_args;
+
+typedef struct dsp_fir_args {
+    const void *src;        /* device, burst-major [B][src_stride] samples of in_kind      */
+    int32_t in_kind;        /* DSP_C64 / DSP_C128 / DSP_I16                                 */
+    int32_t start;          /* < 0: 'same'                                                  */
+    int64_t B, N, src_stride;
+    const int32_t *lens;    /* device [B] or NULL                                           */
+    const double *h;        /* device taps [n_taps]                                         */
+    int32_t n_taps, reserved;
+    const float *in_scale;  /* device scalar multiplied into int16 samples (float32) or NULL */
+    void *tiles;            /* out: tiles [..][rows][64] complex64 (complex128 for C128), or NULL */
+    int64_t rows;
+    const double *scale;    /* device [B] factor applied to the outputs, or NULL            */
+    double *std_out;        /* device [B] np.std of the unscaled output, or NULL            */
+    double *inv_std_out;    /* device [B] 1/std, or NULL                                    */
+    void *workspace;        /* device, dsp_fir_workspace_bytes() bytes (needed for std)     */
+    int64_t workspace_bytes;
+} dsp_fir_args;
+
+int64_t dsp_fir_workspace_bytes(int in_kind, int64_t B, int64_t N, int n_taps);
+/* FIR from burst-major samples straight into tiles (+ per-burst std); asynchronous.
+ * Returns DSP_E_ARG if the filter is too long for the LDS-tiled kernel (n_taps > ~80). */
+int dsp_fir_tiles_dev(dsp_ctx *ctx, const dsp_fir_args *args);
 
 /* Launches the fused recurrence kernel on the context stream (asynchronous).    */
 int dsp_sync_tiles_dev(dsp_ctx *ctx, const dsp_sync_args *args);
