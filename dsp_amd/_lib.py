@@ -120,12 +120,13 @@ def _declare(L):
     L.dsp_fir_workspace_bytes.argtypes = [ci, i64, i64, ci]
     L.dsp_fir_workspace_bytes.restype = i64
     L.dsp_fir_tiles_dev.argtypes = [vp, C.POINTER(FirArgs)]
+    L.dsp_synth_bursts_dev.argtypes = [vp, C.c_uint64, i64, i64, ci, ci, vp, ci, dbl, vp]
     for name in ("dsp_device_count", "dsp_create", "dsp_set_stream", "dsp_synchronize",
                  "dsp_set_option", "dsp_malloc", "dsp_free", "dsp_memset", "dsp_h2d", "dsp_d2h",
                  "dsp_timer_start", "dsp_timer_stop", "dsp_rrc_taps", "dsp_fll_gains",
                  "dsp_gardner", "dsp_fll", "dsp_sync_chain", "dsp_tile_bursts_dev",
                  "dsp_untile_dev", "dsp_sync_tiles_dev", "dsp_load_iq_i16", "dsp_load_iq_f32",
-                 "dsp_fir_same_std", "dsp_rx_chain", "dsp_fir_tiles_dev"):
+                 "dsp_fir_same_std", "dsp_rx_chain", "dsp_fir_tiles_dev", "dsp_synth_bursts_dev"):
         getattr(L, name).restype = ci
 
 

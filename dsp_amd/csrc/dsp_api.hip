@@ -725,4 +725,16 @@ int dsp_rx_chain(dsp_ctx *c, const void *x, int in_kind, int64_t B, int64_t N, i
                         ef, dec, n_out, out_stride);
 }
 
+int dsp_synth_bursts_dev(dsp_ctx *c, uint64_t seed, int64_t b0, int64_t B, int n_sym, int sps,
+                         const double *d_taps, int n_taps, double esn0_db, void *d_out_c64)
+{
+    if (!c || !d_taps || !d_out_c64) return fail(DSP_E_ARG, "synth: NULL argument");
+    if (B < 0 || B > 65535 || n_sym < 2 || sps < 1 || n_taps < 1 || n_taps > 512)
+        return fail(DSP_E_ARG, "synth: bad B / n_sym / sps / n_taps");
+    const float sigma = (float)sqrt(pow(10.0, -esn0_db / 10.0));
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_synth(seed, b0, (int)B, n_sym, sps, d_taps, n_taps, sigma, d_out_c64, c->stream));
+    return DSP_OK;
+}
+
 }  // extern "C"

@@ -87,3 +87,7 @@ hipError_t launch_burst_scale(void *y, int c128, int64_t ld, const int *lens, in
 hipError_t launch_burst_cast(const void *src, int64_t src_ld, void *dst, int64_t dst_ld, int B, int n, hipStream_t s);
 hipError_t launch_iq_i16(const void *raw, int64_t n, int normalize, unsigned *peak2, float *iscale, void *out,
                          hipStream_t s);
+
+// synthetic burst generator (synth_kernels.hip)
+hipError_t launch_synth(uint64_t seed, int64_t b0, int B, int n_sym, int sps, const double *taps, int M,
+                        float sigma, void *out, hipStream_t s);

@@ -59,3 +59,34 @@ def synth_bursts(b0: int, count: int, taps: np.ndarray, **kw) -> np.ndarray:
     """[count][n_sym*sps] complex64, bursts b0 .. b0+count-1."""
     rows = [synth_burst(b0 + i, taps, **kw) for i in range(count)]
     return np.stack(rows, axis=0)
+
+
+# ---------------------------------------------------------------------------
+# host mirror of the device generator's counter-based RNG (dsp_amd/csrc/synth_kernels.hip)
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x):
+    x = (np.asarray(x, dtype=np.uint64) + np.uint64(0x9E3779B97F4A7C15)) & _M64
+    z = x
+    z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+    z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+    return z ^ (z >> np.uint64(31))
+
+
+def device_symbols(seed: int, b: int, n_sym: int) -> np.ndarray:
+    """Quadrant indices (Re<0) + 2*(Im<0) of the symbols dsp_synth_bursts_dev transmits in burst b."""
+    with np.errstate(over="ignore"):
+        key = _splitmix64(np.uint64(seed) + np.uint64(b))
+        idx = np.arange(n_sym, dtype=np.uint64)
+        h = _splitmix64(key + (np.uint64(1) << np.uint64(40)) + idx)
+    return (h & np.uint64(3)).astype(np.uint8)
+
+
+def device_params(seed: int, b: int):
+    """(tau, f, phi) of burst b of the device generator."""
+    with np.errstate(over="ignore"):
+        key = _splitmix64(np.uint64(seed) + np.uint64(b))
+        h = _splitmix64(key + (np.uint64(2) << np.uint64(40)) + np.arange(3, dtype=np.uint64))
+    u = ((h >> np.uint64(11)).astype(np.float64) + 1.0) / 9007199254740992.0
+    return u[0] - 0.5, (u[1] - 0.5) * 1e-3, u[2] * 2 * np.pi

@@ -188,6 +188,14 @@ int64_t dsp_fir_workspace_bytes(int in_kind, int64_t B, int64_t N, int n_taps);
  * Returns DSP_E_ARG if the filter is too long for the LDS-tiled kernel (n_taps > ~80). */
 int dsp_fir_tiles_dev(dsp_ctx *ctx, const dsp_fir_args *args);
 
+/* Synthetic QPSK bursts generated on the device (benchmarks / full-size tests; recipe of
+ * SURVEY.md 8d after worker.py:339-427, counter-based RNG): bursts b0 .. b0+B-1 of n_sym*sps
+ * complex64 samples, burst-major, at the TX output + channel (before the RX matched filter).
+ * d_taps: device TX RRC taps.  No counterpart function in the reference (its generator is
+ * numpy-random based); asynchronous; B <= 65535 per call.                          */
+int dsp_synth_bursts_dev(dsp_ctx *ctx, uint64_t seed, int64_t b0, int64_t B, int n_sym, int sps,
+                         const double *d_taps, int n_taps, double esn0_db, void *d_out_c64);
+
 /* Launches the fused recurrence kernel on the context stream (asynchronous).    */
 int dsp_sync_tiles_dev(dsp_ctx *ctx, const dsp_sync_args *args);
 
