@@ -154,6 +154,13 @@ def main():
     kern_ms = ev_ms / args.steps
     value = samples / (wall / args.steps) / 1e6
     achieved = B * N * A_FULL / (kern_ms * 1e-3) / 1e9
+    traffic = None        # HBM bytes per launch from the committed PMC profile of this workload
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if tj["bursts_per_gpu"] == B and tj["samples_per_burst"] == N:
+            traffic = tj["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     line = {
         "metric": "Msamples/s (node) FLL+Gardner on batched QPSK bursts",
         "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
@@ -167,7 +174,7 @@ def main():
                    "matched_filter_ms": fir_ms,
                    "parallelism": f"bursts sharded x{world}, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": achieved * 1e9 / HBM_PEAK, "traffic": None,
+                     "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic,
                      "kernel": "sync_split_kernel<c64,gardner2>" if args.split != 0 else "sync_kernel<c64,gardner2,fll>", "kernel_ms": kern_ms,
                      "bytes_per_sample": A_FULL},
     }
