@@ -80,6 +80,42 @@ DSP_HD MathK math_consts_literal()
 // the independent sin / cos / atan chains, which matters more than the instruction count.)
 DSP_HD double fma3(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
+// wave-uniform vote (device) / plain predicate (host build of the same source)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DSP_WAVE_ALL(p) (__all((int)(p)) != 0)
+#else
+#define DSP_WAVE_ALL(p) (p)
+#endif
+
+// x - floor(x) for x >= 0, exact
+DSP_HD double fract_pos(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fract(x);
+#else
+    return x - __builtin_floor(x);
+#endif
+}
+
+// num / den to <= 1 ulp without the scaling / fix-up steps of the IEEE sequence (operands
+// here are sample magnitudes, far from the exponent limits): rcp + 2 Newton steps + one
+// residual correction.
+DSP_HD double div_fast(double num, double den)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(den);
+    double e = __builtin_fma(-den, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-den, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    double q = num * r;
+    double rem = __builtin_fma(-den, q, num);
+    return __builtin_fma(rem, r, q);
+#else
+    return num / den;
+#endif
+}
+
 // ---------------------------------------------------------------------------
 // sin and cos of a float64 angle in radians, any magnitude up to ~1e15.
 // Argument reduction by pi/2 in three FMA steps (pi/2 split into three
@@ -106,36 +142,49 @@ DSP_HD void sincos_f64(const MathK &K, double x, double &s, double &c)
     pc = fma3(z, pc, K.v[K_C2]);
     pc = fma3(z, pc, K.v[K_C1]);
     double cs = fma3(z * z, pc, fma3(-0.5, z, 1.0));
-    // quadrant = k mod 4, valid for any |k| < 2^52
-    double kq = k * 0.25;
-    int q = (int)((kq - d_floor(kq)) * 4.0);
+    // quadrant = k mod 4: adding 1.5 * 2^52 leaves k (two's complement) in the low mantissa
+    // bits, valid for |k| < 2^51
+    double kk = k + 6755399441055744.0;
+    unsigned long long kb;
+    __builtin_memcpy(&kb, &kk, 8);
+    unsigned q = (unsigned)kb;
     double s0 = (q & 1) ? cs : sn;
     double c0 = (q & 1) ? sn : cs;
-    s = (q & 2) ? -s0 : s0;
-    c = ((q + 1) & 2) ? -c0 : c0;
+    // sign flips as bit operations on the high word
+    unsigned long long sb, cb;
+    __builtin_memcpy(&sb, &s0, 8);
+    __builtin_memcpy(&cb, &c0, 8);
+    sb ^= (unsigned long long)((q << 30) & 0x80000000u) << 32;
+    cb ^= (unsigned long long)(((q + 1) << 30) & 0x80000000u) << 32;
+    __builtin_memcpy(&s, &sb, 8);
+    __builtin_memcpy(&c, &cb, 8);
 }
 
 // ---------------------------------------------------------------------------
-// atan2(y, x), all quadrants, fdlibm atan kernel with one division; the
-// interval reduction is folded into the quotient by selects (no branches).
-DSP_HD double atan2_f64(const MathK &K, double y, double x)
+// atan2(y, x), all quadrants, fdlibm atan kernel with one division.  For t = min/max in
+// [0,1]:  t >= 7/16 -> atan(1) + atan((t-1)/(t+1)) (|arg| <= 0.392, inside the kernel's
+// |x| < 7/16 range), else atan(t); the interval choice is folded into the quotient by selects.
+// `easy`: the caller knows x > 0 and |y| <= x for every lane of the wave that matters
+// (the FLL's phase error lies in [-pi/4, pi/4]); the octant logic is then skipped.  Both
+// paths compute identical values for such inputs.
+DSP_HD double atan2_f64(const MathK &K, double y, double x, bool easy)
 {
     double ax = d_abs(x), ay = d_abs(y);
-    bool swap = ay > ax;
-    double mx = swap ? ay : ax;
-    double mn = swap ? ax : ay;
-    // t = mn/mx in [0,1]:  t >= 11/16 -> atan(1) + atan((t-1)/(t+1));
-    // 7/16 <= t < 11/16 -> atan(1/2) + atan((2t-1)/(2+t)); else atan(t)
-    double m16 = 16.0 * mn;
+    bool swap = false;
+    double mx = ax, mn = ay;
+    if (!easy) {
+        swap = ay > ax;
+        mx = swap ? ay : ax;
+        mn = swap ? ax : ay;
+    }
     bool zero = mx == 0.0;                       // atan2(+-0, +-0): quotient 0, signs below
-    bool c2 = (m16 >= 11.0 * mx) && !zero;
-    bool c1 = (m16 >= 7.0 * mx) && !zero;
-    double num = c2 ? mn - mx : (c1 ? 2.0 * mn - mx : mn);
-    double den = c2 ? mn + mx : (c1 ? 2.0 * mx + mn : mx);
-    double hi = c2 ? K.v[K_PIO4_HI] : (c1 ? K.v[K_ATAN_HALF_HI] : 0.0);
-    double lo = c2 ? K.v[K_PIO4_LO] : (c1 ? K.v[K_ATAN_HALF_LO] : 0.0);
+    bool c2 = (16.0 * mn >= 7.0 * mx) && !zero;
+    double num = c2 ? mn - mx : mn;
+    double den = c2 ? mn + mx : mx;
+    double hi = c2 ? K.v[K_PIO4_HI] : 0.0;
+    double lo = c2 ? K.v[K_PIO4_LO] : 0.0;
     den = zero ? 1.0 : den;
-    double t = num / den;
+    double t = div_fast(num, den);
     double z = t * t;
     double w = z * z;
     double s1 = fma3(w, K.v[K_AT10], K.v[K_AT8]);
@@ -151,32 +200,36 @@ DSP_HD double atan2_f64(const MathK &K, double y, double x)
     s2 = w * s2;
     // atan(t) = hi - ((t*(s1+s2) - lo) - t)
     double a = hi - ((t * (s1 + s2) - lo) - t);
-    a = swap ? K.v[K_PIO2_HI] - (a - K.v[K_PIO2_LO]) : a;
-    a = __builtin_signbit(x) ? K.v[K_PI_HI] - (a - K.v[K_PI_LO]) : a;
+    if (!easy) {
+        a = swap ? K.v[K_PIO2_HI] - (a - K.v[K_PIO2_LO]) : a;
+        a = __builtin_signbit(x) ? K.v[K_PI_HI] - (a - K.v[K_PI_LO]) : a;
+    }
     return d_copysign(a, y);
 }
 
 // ---------------------------------------------------------------------------
 // One iteration of fll_func's loop body (fll_func.py:15-26) for sample x at
 // absolute index i.  state: curr_freq, integrator.  kp, ki: fll_func.py:5-6.
+// `live`: this lane's result will be used (dead lanes do not veto the wave's fast path).
 struct FllOut { double sr, si, ef, freq; int quad; };
 
 DSP_HD FllOut fll_step(const MathK &K, double xr, double xi, double idx, double &curr_freq,
-                       double &integrator, double kp, double ki)
+                       double &integrator, double kp, double ki, bool live = true)
 {
     double phase = K.v[K_TWO_PI] * curr_freq * idx;     // :16
     double s, c;
     sincos_f64(K, phase, s, c);                         // exp(-1j*phase) = (c, -s)
     double sr = xr * c + xi * s;                        // xr*wr - xi*wi, wi = -s
     double si = xi * c - xr * s;                        // xr*wi + xi*wr
-    double gr = (double)((sr > 0.0) - (sr < 0.0));      // np.sign (sign(0) = 0)
-    double gi = (double)((si > 0.0) - (si < 0.0));
-    gr = (sr != sr) ? sr : gr;
-    gi = (si != si) ? si : gi;
-    double cr = gr * K.v[K_SCL], ci = gi * K.v[K_SCL];
+    // :19 decided = (sign(re) + 1j*sign(im)) / sqrt(2); np.sign(0) = 0, NaN stays NaN through
+    // the products below
+    double cr = d_copysign(K.v[K_SCL], sr), ci = d_copysign(K.v[K_SCL], si);
+    cr = (sr == 0.0) ? 0.0 : cr;
+    ci = (si == 0.0) ? 0.0 : ci;
     double zr = sr * cr + si * ci;                      // sample * conj(decided)
     double zi = si * cr - sr * ci;
-    double error = atan2_f64(K, zi, zr);                // :21
+    bool easy = DSP_WAVE_ALL(!live || (zr > 0.0 && d_abs(zi) <= zr));
+    double error = atan2_f64(K, zi, zr, easy);          // :21
     integrator += error * ki;                           // :22
     double ef_n = error * kp + integrator;              // :23
     curr_freq += ef_n;                                  // :25

@@ -40,23 +40,28 @@ __device__ __forceinline__ void st_b8(uint8_t *p, unsigned v)
 {
     asm volatile("global_store_byte %0, %1, off" :: "v"(p), "v"(v) : "memory");
 }
-__device__ __forceinline__ void st_val(float *p, double v)
+// `keep` false -> the lane stores zeros (rows past a burst's last symbol read as zero)
+__device__ __forceinline__ void st_val(float *p, double v, bool keep = true)
 {
     float f = (float)v;
+    f = keep ? f : 0.0f;
     asm volatile("global_store_dword %0, %1, off" :: "v"(p), "v"(f) : "memory");
 }
-__device__ __forceinline__ void st_val(double *p, double v)
+__device__ __forceinline__ void st_val(double *p, double v, bool keep = true)
 {
+    v = keep ? v : 0.0;
     asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(v) : "memory");
 }
-__device__ __forceinline__ void st_cplx(f2v *p, double re, double im)
+__device__ __forceinline__ void st_cplx(f2v *p, double re, double im, bool keep = true)
 {
     f2v v = {(float)re, (float)im};
+    v.x = keep ? v.x : 0.0f;
+    v.y = keep ? v.y : 0.0f;
     asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(v) : "memory");
 }
-__device__ __forceinline__ void st_cplx(d2v *p, double re, double im)
+__device__ __forceinline__ void st_cplx(d2v *p, double re, double im, bool keep = true)
 {
-    d2v v = {re, im};
+    d2v v = {keep ? re : 0.0, keep ? im : 0.0};
     asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(p), "v"(v) : "memory");
 }
 
@@ -122,13 +127,14 @@ struct Tile {
         z.im = (double)v.y * scale;
         return z;
     }
-    // straight-line access, row known to be inside the window
+    // straight-line access, row known to be inside the window; SC: apply the per-burst scale
+    template <bool SC>
     __device__ __forceinline__ cd lds_at(int row) const
     {
         IN v = ((const IN *)ring)[(row & RM) * 64 + lane];
         cd z;
-        z.re = (double)v.x * scale;
-        z.im = (double)v.y * scale;
+        z.re = SC ? (double)v.x * scale : (double)v.x;
+        z.im = SC ? (double)v.y * scale : (double)v.y;
         return z;
     }
     // issue the DMA pieces for rows [F, F_new)
@@ -172,7 +178,7 @@ struct TimingConst {
 // One pass of the timing loop body for every lane of the wave.  Fast path: no
 // lane needs the wrap loops and all rows are inside the ring window -> straight
 // line code, results committed by select.  Otherwise the generic per-lane code.
-template <typename IN, int VARIANT, bool LAGR>
+template <typename IN, int VARIANT, bool LAGR, bool SC>
 __device__ __forceinline__ dspm::GOut timing_iter(const Tile<IN> &tl, dspm::GState &gs, const TimingConst &tc,
                                                   const dspm::LagrangeW *Lp)
 {
@@ -205,19 +211,19 @@ __device__ __forceinline__ dspm::GOut timing_iter(const Tile<IN> &tl, dspm::GSta
             i_c = (double)((gs.k + 1) * sps) + mu;             // idx_next
             i_b = base + mu + tc.halfd;                        // idx_mid
             ok = cont && !(i_c + 1.0 >= lend || i_b + 1.0 >= lend);
-            const double fa = dspm::d_floor(i_a), fb = dspm::d_floor(i_b), fc = dspm::d_floor(i_c);
-            r_a = __double2int_rz(fa); r_b = __double2int_rz(fb); r_c = __double2int_rz(fc);
+            r_a = __double2int_rd(i_a); r_b = __double2int_rd(i_b); r_c = __double2int_rd(i_c);   // np.floor
             const bool inwin = (r_a >= win_lo) && (r_c + 1 < win_hi) && (r_a >= 0);
             fast = !__any(ok && !inwin);
         }
     }
     if (fast) {
-        cd a0 = tl.lds_at(r_a), a1 = tl.lds_at(r_a + 1);
-        cd b0 = tl.lds_at(r_b), b1 = tl.lds_at(r_b + 1);
-        cd c0 = tl.lds_at(r_c), c1 = tl.lds_at(r_c + 1);
-        cd xa = dspm::lerp(a0, a1, i_a - (double)r_a);
-        cd xb = dspm::lerp(b0, b1, i_b - (double)r_b);
-        cd xc = dspm::lerp(c0, c1, i_c - (double)r_c);
+        cd a0 = tl.template lds_at<SC>(r_a), a1 = tl.template lds_at<SC>(r_a + 1);
+        cd b0 = tl.template lds_at<SC>(r_b), b1 = tl.template lds_at<SC>(r_b + 1);
+        cd c0 = tl.template lds_at<SC>(r_c), c1 = tl.template lds_at<SC>(r_c + 1);
+        // the three indices are >= 0 on every lane that commits: idx - trunc(idx) = fract(idx)
+        cd xa = dspm::lerp(a0, a1, dspm::fract_pos(i_a));
+        cd xb = dspm::lerp(b0, b1, dspm::fract_pos(i_b));
+        cd xc = dspm::lerp(c0, c1, dspm::fract_pos(i_c));
         const double e = dspm::ted_error(xa, xb, xc);
         cd rec; rec.re = 0.0; rec.im = 0.0;
         double mu_n, mu_hist;
@@ -229,7 +235,7 @@ __device__ __forceinline__ dspm::GOut timing_iter(const Tile<IN> &tl, dspm::GSta
             const int hi_lim = win_hi < len ? win_hi : len;
             const bool ofast = (i_o > -1.0e9 && i_o < 1.0e9) && r_o >= win_lo && r_o + 1 < hi_lim;
             if (!__any(ok && !ofast)) {
-                rec = dspm::lerp(tl.lds_at(r_o), tl.lds_at(r_o + 1), i_o - (double)r_o);
+                rec = dspm::lerp(tl.template lds_at<SC>(r_o), tl.template lds_at<SC>(r_o + 1), i_o - (double)r_o);
             } else if (ok) {
                 rec = dspm::g2_interp(i_o, len, (const dspm::LagrangeW *)nullptr, FetchFn<IN>{tl});
             }
@@ -244,11 +250,10 @@ __device__ __forceinline__ dspm::GOut timing_iter(const Tile<IN> &tl, dspm::GSta
         }
         gs.mu = ok ? mu_n : mu;
         gs.active = ok;
-        go.produced = ok;
-        go.err = ok ? e : 0.0;
-        go.mu = ok ? mu_hist : 0.0;
-        go.rec.re = ok ? rec.re : 0.0;
-        go.rec.im = ok ? rec.im : 0.0;
+        go.produced = ok;          // err / mu / rec of a lane that did not produce are never
+        go.err = e;                // consumed: the stores zero them by predicate
+        go.mu = mu_hist;
+        go.rec = rec;
     } else {
         if (VARIANT == DSP_VARIANT_GARDNER2)
             go = dspm::gardner2_iter(gs, len, sps, alpha, Lp, FetchFn<IN>{tl});
@@ -264,7 +269,7 @@ __device__ __forceinline__ FllLane fll_iter(const dspm::MathK &MK, bool pending,
                                             double &freq, double &integ, double kp, double ki)
 {
     double nf = freq, ni = integ;
-    dspm::FllOut fo = dspm::fll_step(MK, x.re, x.im, idx, nf, ni, kp, ki);
+    dspm::FllOut fo = dspm::fll_step(MK, x.re, x.im, idx, nf, ni, kp, ki, pending);
     freq = pending ? nf : freq;
     integ = pending ? ni : integ;
     FllLane o;
@@ -303,7 +308,7 @@ __device__ __forceinline__ void timing_init(TimingConst &tc, dspm::GState &gs, c
 
 // ---------------------------------------------------------------------------
 // Unified kernel: one wave per tile does the timing loop and the FLL.
-template <typename IN, int VARIANT, bool FLL, bool LAGR>
+template <typename IN, int VARIANT, bool FLL, bool LAGR, bool SC>
 __global__ __launch_bounds__(64) void sync_kernel(SyncParams P)
 {
     typedef typename InT<IN>::OS OS;     // output scalar (float for c64 in, double for c128 in)
@@ -375,15 +380,14 @@ __global__ __launch_bounds__(64) void sync_kernel(SyncParams P)
             if (VARIANT == DSP_VARIANT_NONE) {
                 const bool have = pending && (it + 1 < len);
                 if (it + 1 >= tl.win_lo && it + 1 < tl.win_hi) {            // uniform
-                    cd v = tl.lds_at(it + 1);
-                    go.rec.re = have ? v.re : 0.0; go.rec.im = have ? v.im : 0.0;
+                    go.rec = tl.template lds_at<SC>(it + 1);
                 } else if (have) {
                     go.rec = tl.fetch(it + 1);
                 }
                 go.produced = have;
             } else {
                 if (gs.active && rec_row >= cap_rows) { gs.active = false; overflow = true; }
-                go = timing_iter<IN, VARIANT, LAGR>(tl, gs, tc, Lp);
+                go = timing_iter<IN, VARIANT, LAGR, SC>(tl, gs, tc, Lp);
             }
             // ---- stores: unconditional, one instruction per enabled output -
             const int frow = fll_row < 0 ? 0 : fll_row;
@@ -397,9 +401,9 @@ __global__ __launch_bounds__(64) void sync_kernel(SyncParams P)
             if (VARIANT != DSP_VARIANT_NONE) {
                 const int rrow = rec_row < cap_rows ? rec_row : cap_rows;   // last row = scratch
                 const size_t g_off = obase + (size_t)it * 64;
-                if (o_rec) st_cplx(o_rec + obase + (size_t)rrow * 64, go.rec.re, go.rec.im);
-                if (o_terr) st_val(o_terr + g_off, go.err);
-                if (o_mu) st_val(o_mu + g_off, go.mu);
+                if (o_rec) st_cplx(o_rec + obase + (size_t)rrow * 64, go.rec.re, go.rec.im, go.produced);
+                if (o_terr) st_val(o_terr + g_off, go.err, go.produced);
+                if (o_mu) st_val(o_mu + g_off, go.mu, go.produced);
             }
             pending = go.produced;
             rec_prev = go.rec;
@@ -426,7 +430,7 @@ __global__ __launch_bounds__(64) void sync_kernel(SyncParams P)
 //   LDS: [ring][queue 2*TQ*64 complex128][flags 2*TQ*64 bytes][more[2]]
 //   Block qb: wave 0 fills queue[qb&1], s_barrier; wave 1 drains it while wave 0
 //   fills the other half.  Every block both waves execute exactly one barrier.
-template <typename IN, int VARIANT>
+template <typename IN, int VARIANT, bool SC>
 __global__ __launch_bounds__(128) void sync_split_kernel(SyncParams P)
 {
     typedef typename InT<IN>::OS OS;
@@ -475,13 +479,13 @@ __global__ __launch_bounds__(128) void sync_split_kernel(SyncParams P)
             for (int t = 0; t < TQ; t++, it++) {
                 const int rec_row = it + ROFF;
                 if (gs.active && rec_row >= cap_rows) { gs.active = false; overflow = true; }
-                dspm::GOut go = timing_iter<IN, VARIANT, false>(tl, gs, tc, nullptr);
+                dspm::GOut go = timing_iter<IN, VARIANT, false, SC>(tl, gs, tc, nullptr);
                 const int rrow = rec_row < cap_rows ? rec_row : cap_rows;
                 const int erow = it < cap_rows ? it : cap_rows;
                 const size_t g_off = obase + (size_t)erow * 64;
-                if (o_rec) st_cplx(o_rec + obase + (size_t)rrow * 64, go.rec.re, go.rec.im);
-                if (o_terr) st_val(o_terr + g_off, go.err);
-                if (o_mu) st_val(o_mu + g_off, go.mu);
+                if (o_rec) st_cplx(o_rec + obase + (size_t)rrow * 64, go.rec.re, go.rec.im, go.produced);
+                if (o_terr) st_val(o_terr + g_off, go.err, go.produced);
+                if (o_mu) st_val(o_mu + g_off, go.mu, go.produced);
                 d2v qv = {go.rec.re, go.rec.im};
                 q_data[(buf * TQ + t) * 64 + lane] = qv;
                 q_flag[(buf * TQ + t) * 64 + lane] = go.produced ? 1 : 0;
@@ -579,9 +583,11 @@ static hipError_t launch_v(const SyncParams &P, size_t lds, hipStream_t s)
 {
     int ntiles = (P.B + 63) / 64;
     if (P.half_len > 0)
-        hipLaunchKernelGGL((sync_kernel<IN, VARIANT, FLL, true>), dim3(ntiles), dim3(64), lds, s, P);
+        hipLaunchKernelGGL((sync_kernel<IN, VARIANT, FLL, true, true>), dim3(ntiles), dim3(64), lds, s, P);
+    else if (P.scale)
+        hipLaunchKernelGGL((sync_kernel<IN, VARIANT, FLL, false, true>), dim3(ntiles), dim3(64), lds, s, P);
     else
-        hipLaunchKernelGGL((sync_kernel<IN, VARIANT, FLL, false>), dim3(ntiles), dim3(64), lds, s, P);
+        hipLaunchKernelGGL((sync_kernel<IN, VARIANT, FLL, false, false>), dim3(ntiles), dim3(64), lds, s, P);
     return hipGetLastError();
 }
 
@@ -590,10 +596,13 @@ static hipError_t launch_in(const SyncParams &P, int variant, bool fll, size_t l
 {
     if (P.TQ > 0) {        // two waves per tile (timing wave + FLL wave)
         int ntiles = (P.B + 63) / 64;
-        if (variant == DSP_VARIANT_GARDNER2)
-            hipLaunchKernelGGL((sync_split_kernel<IN, DSP_VARIANT_GARDNER2>), dim3(ntiles), dim3(128), lds, s, P);
-        else
-            hipLaunchKernelGGL((sync_split_kernel<IN, DSP_VARIANT_TED>), dim3(ntiles), dim3(128), lds, s, P);
+        if (variant == DSP_VARIANT_GARDNER2) {
+            if (P.scale) hipLaunchKernelGGL((sync_split_kernel<IN, DSP_VARIANT_GARDNER2, true>), dim3(ntiles), dim3(128), lds, s, P);
+            else hipLaunchKernelGGL((sync_split_kernel<IN, DSP_VARIANT_GARDNER2, false>), dim3(ntiles), dim3(128), lds, s, P);
+        } else {
+            if (P.scale) hipLaunchKernelGGL((sync_split_kernel<IN, DSP_VARIANT_TED, true>), dim3(ntiles), dim3(128), lds, s, P);
+            else hipLaunchKernelGGL((sync_split_kernel<IN, DSP_VARIANT_TED, false>), dim3(ntiles), dim3(128), lds, s, P);
+        }
         return hipGetLastError();
     }
     switch (variant) {

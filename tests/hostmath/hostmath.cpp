@@ -17,7 +17,7 @@ void hm_sincos(const double *x, int64_t n, double *s, double *c)
 
 void hm_atan2(const double *y, const double *x, int64_t n, double *out)
 {
-    for (int64_t i = 0; i < n; i++) out[i] = atan2_f64(KK, y[i], x[i]);
+    for (int64_t i = 0; i < n; i++) out[i] = atan2_f64(KK, y[i], x[i], false);
 }
 
 // fll_func over a complex128 array with the device step function
