@@ -452,7 +452,9 @@ __global__ __launch_bounds__(128) void sync_split_kernel(SyncParams P)
     unsigned char *q_base = smem + (size_t)P.ring_rows * 64 * sizeof(IN) * (ring ? 1 : 0);
     d2v *q_data = (d2v *)q_base;                                    // [2][TQ][64]
     unsigned char *q_flag = q_base + (size_t)2 * TQ * 64 * sizeof(d2v);   // [2][TQ][64]
-    volatile int *q_more = (volatile int *)(q_flag + (size_t)2 * TQ * 64);   // [2]
+    // explicit LDS pointer: a generic (flat) access would have to wait for vmcnt(0) as well
+    typedef __attribute__((address_space(3))) int lds_int;
+    lds_int *q_more = (lds_int *)(q_flag + (size_t)2 * TQ * 64);               // [2]
     constexpr int ROFF = (VARIANT == DSP_VARIANT_TED) ? 0 : 1;      // FLL row of queue entry `it` = it + ROFF
 
     if (role == 0) {
