@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--ring-rows", type=int, default=0)
     ap.add_argument("--lds-pad", type=int, default=-1)
     ap.add_argument("--split", type=int, default=-1, help="-1 auto, 0 one wave per tile, 1 two")
+    ap.add_argument("--prio-period", type=int, default=0, help="priority rotation period (DMA blocks)")
+    ap.add_argument("--queue-block", type=int, default=0, help="split kernel hand-off block (0 auto)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -96,6 +98,10 @@ def main():
     if args.lds_pad >= 0:
         ctx.set_option("lds_pad", args.lds_pad)
     ctx.set_option("split", args.split)
+    if args.prio_period:
+        ctx.set_option("prio_period", args.prio_period)
+    if args.queue_block:
+        ctx.set_option("queue_block", args.queue_block)
     B = args.bursts
     b_lo, b_hi = shard_range(B * world, rank, world)      # this rank's bursts of the whole job
 

@@ -18,6 +18,12 @@ struct dsp_ctx {
     int ring_rows;      // 0 = automatic
     int lds_pad;        // extra dynamic LDS per workgroup (bytes) to steer workgroups per CU
     int split;          // -1 auto / 1: two waves per tile where applicable; 0: one wave per tile
+    int queue_block;    // split kernel: symbols per hand-off block, 0 = automatic
+    int prio_period;    // split kernel: priority rotation period in DMA blocks (power of two), 0 = off
+#ifdef DSP_TRACE
+    unsigned long long *trace;
+    int trace_stamps;
+#endif
 };
 
 static thread_local char g_err[512] = "";
@@ -74,6 +80,12 @@ int dsp_create(int device_id, dsp_ctx **out)
     c->ring_rows = 0;
     c->lds_pad = -1;
     c->split = -1;
+    c->queue_block = 0;
+    c->prio_period = 0;
+#ifdef DSP_TRACE
+    c->trace = nullptr;
+    c->trace_stamps = 0;
+#endif
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
@@ -124,6 +136,18 @@ int dsp_set_option(dsp_ctx *c, const char *name, int64_t value)
         c->lds_pad = (int)value;
     } else if (!strcmp(name, "split")) {
         c->split = (int)value;
+#ifdef DSP_TRACE
+    } else if (!strcmp(name, "trace_ptr")) {     // diagnostic build: device buffer for wave stamps
+        c->trace = (unsigned long long *)(uintptr_t)value;
+    } else if (!strcmp(name, "trace_stamps")) {
+        c->trace_stamps = (int)value;
+#endif
+    } else if (!strcmp(name, "prio_period")) {
+        if (value < 0 || value > 4096 || (value & (value - 1))) return fail(DSP_E_ARG, "prio_period must be 0 or a power of two");
+        c->prio_period = (int)value;
+    } else if (!strcmp(name, "queue_block")) {
+        if (value < 0 || value > 64) return fail(DSP_E_ARG, "queue_block must be in [0,64]");
+        c->queue_block = (int)value;
     } else {
         return fail(DSP_E_ARG, "unknown option '%s'", name);
     }
@@ -294,6 +318,10 @@ int dsp_sync_tiles_dev(dsp_ctx *c, const dsp_sync_args *a)
     P.sig = fll ? a->sig : nullptr; P.freq = fll ? a->freq : nullptr; P.ef = fll ? a->ef : nullptr;
     P.dec = fll ? a->dec : nullptr;
     P.out_rows = (int)a->out_rows; P.n_out = a->n_out; P.status = a->status;
+#ifdef DSP_TRACE
+    P.trace = c->trace;
+    P.trace_stamps = c->trace_stamps;
+#endif
 
     // ---- kernel shape -------------------------------------------------------
     // One workgroup per tile; its dynamic LDS (input ring [+ hand-off queue]) also sets how
@@ -307,7 +335,7 @@ int dsp_sync_tiles_dev(dsp_ctx *c, const dsp_sync_args *a)
     const int n_store = split ? n_store_t : n_store_t + n_store_f;
     int per_cu = (ntiles + 255) / 256;
     if (per_cu < 1) per_cu = 1;
-    size_t budget = ((size_t)160 * 1024 / per_cu) & ~(size_t)511;
+    size_t budget = ((size_t)160 * 1024 / per_cu) & ~(size_t)2047;   // LDS is allocated in coarse blocks
     if (budget > 64 * 1024) budget = 64 * 1024;
     int R = c->ring_rows;
     if (R == 0) {
@@ -323,11 +351,16 @@ int dsp_sync_tiles_dev(dsp_ctx *c, const dsp_sync_args *a)
     size_t lds = (size_t)pl.lds_bytes;
     P.TQ = 0;
     if (split) {
-        // queue block: the largest divisor of T whose double buffer still fits the budget
-        int TQ = 1;
-        for (int d = pl.T; d >= 1; d--)
-            if (pl.T % d == 0 && lds + (size_t)2 * d * 64 * 17 + 16 <= budget) { TQ = d; break; }
+        // queue block: as many symbols as the double buffer can hold inside the budget
+        int TQ = c->queue_block;
+        if (TQ == 0) {
+            TQ = 1;
+            for (int d = 16; d >= 1; d--)
+                if (lds + (size_t)2 * d * 64 * 17 + 16 <= budget) { TQ = d; break; }
+        }
+        while (TQ > 1 && lds + (size_t)2 * TQ * 64 * 17 + 16 > 64 * 1024) TQ--;
         P.TQ = TQ;
+        P.prio_period = c->prio_period;
         lds += (size_t)2 * TQ * 64 * 17 + 16;
     }
     if (c->lds_pad >= 0) lds += (size_t)c->lds_pad;

@@ -40,7 +40,12 @@ struct SyncParams {
     int *status;              // [B] bit0: output capacity reached before the loop ended
     // LDS ring schedule (host-computed, see sync_plan())
     int use_ring, ring_rows, T, C, nwait;
-    int TQ;                   // > 0: split kernel, queue block length (iterations); T % TQ == 0
+    int TQ;                   // > 0: split kernel, queue block length (iterations)
+    int prio_period;          // split kernel: rotate the wave priority every this many DMA blocks (power of 2, 0 = off)
+#ifdef DSP_TRACE
+    unsigned long long *trace; // diagnostic build only: [tile][role][20] = start, end (s_memtime), HW_ID, XCC_ID, 16 segment sums
+    int trace_stamps;          // also stamp the loop segments (slows the kernel: read shares, not totals)
+#endif
 };
 
 struct SyncPlan { int use_ring, ring_rows, T, C, nwait, lds_bytes; };

@@ -75,6 +75,28 @@ DSP_HD MathK math_consts_literal()
     return k;
 }
 
+// In-kernel stamps of the diagnostic build (-DDSP_TRACE, never the product): DSP_TR(tr, i)
+// adds the s_memtime ticks since the previous mark to segment i.  Empty otherwise.
+#if defined(DSP_TRACE)
+struct TrAcc { unsigned long long acc[16]; unsigned long long last; };
+DSP_HD void tr_mark(TrAcc *tr, int i)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (!tr) return;
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t));
+    __builtin_amdgcn_sched_barrier(0);
+    if (i >= 0) tr->acc[i] += t - tr->last;
+    tr->last = t;
+#endif
+}
+#define DSP_TR(tr, i) dspm::tr_mark(tr, i)
+#else
+struct TrAcc { };
+#define DSP_TR(tr, i) ((void)0)
+#endif
+
 // fused multiply-add, one rounding.  (A hand-placed v_fma_f64 through inline asm was
 // measured 21% SLOWER than letting hipcc pick v_fmac_f64 + moves: the compiler interleaves
 // the independent sin / cos / atan chains, which matters more than the instruction count.)
@@ -214,11 +236,12 @@ DSP_HD double atan2_f64(const MathK &K, double y, double x, bool easy)
 struct FllOut { double sr, si, ef, freq; int quad; };
 
 DSP_HD FllOut fll_step(const MathK &K, double xr, double xi, double idx, double &curr_freq,
-                       double &integrator, double kp, double ki, bool live = true)
+                       double &integrator, double kp, double ki, bool live = true, TrAcc *tr = nullptr)
 {
     double phase = K.v[K_TWO_PI] * curr_freq * idx;     // :16
     double s, c;
     sincos_f64(K, phase, s, c);                         // exp(-1j*phase) = (c, -s)
+    DSP_TR(tr, 2);
     double sr = xr * c + xi * s;                        // xr*wr - xi*wi, wi = -s
     double si = xi * c - xr * s;                        // xr*wi + xi*wr
     // :19 decided = (sign(re) + 1j*sign(im)) / sqrt(2); np.sign(0) = 0, NaN stays NaN through
@@ -229,7 +252,9 @@ DSP_HD FllOut fll_step(const MathK &K, double xr, double xi, double idx, double 
     double zr = sr * cr + si * ci;                      // sample * conj(decided)
     double zi = si * cr - sr * ci;
     bool easy = DSP_WAVE_ALL(!live || (zr > 0.0 && d_abs(zi) <= zr));
+    DSP_TR(tr, 3);
     double error = atan2_f64(K, zi, zr, easy);          // :21
+    DSP_TR(tr, 4);
     integrator += error * ki;                           // :22
     double ef_n = error * kp + integrator;              // :23
     curr_freq += ef_n;                                  // :25

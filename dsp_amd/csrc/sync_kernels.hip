@@ -36,6 +36,21 @@ __device__ __forceinline__ void lds_dma_16B(const void *g, unsigned lds_off)
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                  :: "v"(g), "s"(lds_off) : "memory", "m0");
 }
+// n (1..4) consecutive 1 KiB pieces with one M0 / one address: the instruction offset moves
+// the global and the LDS address together
+__device__ __forceinline__ void lds_dma_group(const void *g, unsigned lds_off, int n)
+{
+#define DMA0 "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+#define DMAN(o) "\n\tglobal_load_lds_dwordx4 %0, off offset:" #o
+    switch (n) {
+        case 1: asm volatile(DMA0 :: "v"(g), "s"(lds_off) : "memory", "m0"); break;
+        case 2: asm volatile(DMA0 DMAN(1024) :: "v"(g), "s"(lds_off) : "memory", "m0"); break;
+        case 3: asm volatile(DMA0 DMAN(1024) DMAN(2048) :: "v"(g), "s"(lds_off) : "memory", "m0"); break;
+        default: asm volatile(DMA0 DMAN(1024) DMAN(2048) DMAN(3072) :: "v"(g), "s"(lds_off) : "memory", "m0"); break;
+    }
+#undef DMA0
+#undef DMAN
+}
 __device__ __forceinline__ void st_b8(uint8_t *p, unsigned v)
 {
     asm volatile("global_store_byte %0, %1, off" :: "v"(p), "v"(v) : "memory");
@@ -137,14 +152,20 @@ struct Tile {
         z.im = SC ? (double)v.y * scale : (double)v.y;
         return z;
     }
-    // issue the DMA pieces for rows [F, F_new)
+    // issue the DMA pieces for rows [F, F_new): groups of up to four 1 KiB pieces that do not
+    // cross a 4 KiB boundary of the ring (so never its wrap) share one M0 and one address
     __device__ __forceinline__ void issue(int F_new)
     {
         constexpr int RPP = InT<IN>::RPP;
         F_new = F_new < in_rows ? F_new : in_rows;
-        for (int r = F; r < F_new; r += RPP) {
-            const unsigned char *g = (const unsigned char *)(xt + (size_t)r * 64) + lane * 16;
-            lds_dma_16B(g, lds_base + (unsigned)((r & RM) * 64 * (int)sizeof(IN)));
+        int r = F;
+        while (r < F_new) {
+            int g = 4 - ((r / RPP) & 3);
+            const int left = (F_new - r + RPP - 1) / RPP;
+            g = g < left ? g : left;
+            const unsigned char *gp = (const unsigned char *)(xt + (size_t)r * 64) + lane * 16;
+            lds_dma_group(gp, lds_base + (unsigned)((r & RM) * 64 * (int)sizeof(IN)), g);
+            r += g * RPP;
         }
         F = F_new > F ? F_new : F;
     }
@@ -180,7 +201,7 @@ struct TimingConst {
 // line code, results committed by select.  Otherwise the generic per-lane code.
 template <typename IN, int VARIANT, bool LAGR, bool SC>
 __device__ __forceinline__ dspm::GOut timing_iter(const Tile<IN> &tl, dspm::GState &gs, const TimingConst &tc,
-                                                  const dspm::LagrangeW *Lp)
+                                                  const dspm::LagrangeW *Lp, dspm::TrAcc *tr = nullptr)
 {
     dspm::GOut go; go.produced = false; go.rec.re = 0.0; go.rec.im = 0.0; go.err = 0.0; go.mu = 0.0;
     const int len = tc.len, sps = tc.sps;
@@ -216,10 +237,12 @@ __device__ __forceinline__ dspm::GOut timing_iter(const Tile<IN> &tl, dspm::GSta
             fast = !__any(ok && !inwin);
         }
     }
+    DSP_TR(tr, 1);
     if (fast) {
         cd a0 = tl.template lds_at<SC>(r_a), a1 = tl.template lds_at<SC>(r_a + 1);
         cd b0 = tl.template lds_at<SC>(r_b), b1 = tl.template lds_at<SC>(r_b + 1);
         cd c0 = tl.template lds_at<SC>(r_c), c1 = tl.template lds_at<SC>(r_c + 1);
+        DSP_TR(tr, 2);
         // the three indices are >= 0 on every lane that commits: idx - trunc(idx) = fract(idx)
         cd xa = dspm::lerp(a0, a1, dspm::fract_pos(i_a));
         cd xb = dspm::lerp(b0, b1, dspm::fract_pos(i_b));
@@ -234,8 +257,16 @@ __device__ __forceinline__ dspm::GOut timing_iter(const Tile<IN> &tl, dspm::GSta
             const int r_o = __double2int_rz(i_o);
             const int hi_lim = win_hi < len ? win_hi : len;
             const bool ofast = (i_o > -1.0e9 && i_o < 1.0e9) && r_o >= win_lo && r_o + 1 < hi_lim;
-            if (!__any(ok && !ofast)) {
-                rec = dspm::lerp(tl.template lds_at<SC>(r_o), tl.template lds_at<SC>(r_o + 1), i_o - (double)r_o);
+            DSP_TR(tr, 3);
+            // mu moves by alpha*e per symbol: the output instant almost always lies between the
+            // same two samples as the late one, which are already in registers
+            const bool same = ofast && r_o == r_c;
+            if (!__any(ok && !same)) {
+                rec = dspm::lerp(c0, c1, i_o - (double)r_o);
+            } else if (!__any(ok && !ofast)) {
+                cd o0 = tl.template lds_at<SC>(r_o), o1 = tl.template lds_at<SC>(r_o + 1);
+                DSP_TR(tr, 4);
+                rec = dspm::lerp(o0, o1, i_o - (double)r_o);
             } else if (ok) {
                 rec = dspm::g2_interp(i_o, len, (const dspm::LagrangeW *)nullptr, FetchFn<IN>{tl});
             }
@@ -266,10 +297,11 @@ __device__ __forceinline__ dspm::GOut timing_iter(const Tile<IN> &tl, dspm::GSta
 // FLL step for every lane, committed by select (no divergent control flow)
 struct FllLane { double sr, si, ef, freq; unsigned quad; };
 __device__ __forceinline__ FllLane fll_iter(const dspm::MathK &MK, bool pending, cd x, double idx,
-                                            double &freq, double &integ, double kp, double ki)
+                                            double &freq, double &integ, double kp, double ki,
+                                            dspm::TrAcc *tr = nullptr)
 {
     double nf = freq, ni = integ;
-    dspm::FllOut fo = dspm::fll_step(MK, x.re, x.im, idx, nf, ni, kp, ki, pending);
+    dspm::FllOut fo = dspm::fll_step(MK, x.re, x.im, idx, nf, ni, kp, ki, pending, tr);
     freq = pending ? nf : freq;
     integ = pending ? ni : integ;
     FllLane o;
@@ -419,6 +451,26 @@ __global__ __launch_bounds__(64) void sync_kernel(SyncParams P)
     }
 }
 
+// Wave priority that rotates with progress.  The SIMD arbiter serves the oldest wave of the
+// highest priority first; with several tiles per SIMD that lets the first-launched waves race
+// ahead and leaves the youngest to finish alone at one-wave speed.  Rotating the priority
+// among the co-resident wave slots gives every wave the same share over time.
+__device__ __forceinline__ void rotate_priority(unsigned slot, int phase)
+{
+    switch ((slot + (unsigned)phase) & 3u) {
+        case 0: asm volatile("s_setprio 0"); break;
+        case 1: asm volatile("s_setprio 1"); break;
+        case 2: asm volatile("s_setprio 2"); break;
+        default: asm volatile("s_setprio 3"); break;
+    }
+}
+__device__ __forceinline__ unsigned wave_slot()
+{
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(hw));   // wave slot on its SIMD
+    return hw;
+}
+
 // ---------------------------------------------------------------------------
 // Split kernel: two waves per tile.  Wave 0 runs the timing loop (ring, DMA,
 // rec/err/mu stores) and hands each recovered symbol to wave 1 through a
@@ -456,6 +508,22 @@ __global__ __launch_bounds__(128) void sync_split_kernel(SyncParams P)
     typedef __attribute__((address_space(3))) int lds_int;
     lds_int *q_more = (lds_int *)(q_flag + (size_t)2 * TQ * 64);               // [2]
     constexpr int ROFF = (VARIANT == DSP_VARIANT_TED) ? 0 : 1;      // FLL row of queue entry `it` = it + ROFF
+    const unsigned slot = wave_slot();
+    int prio_n = P.prio_period, prio_c = 1, prio_ph = 0;
+#ifdef DSP_TRACE
+    const unsigned long long tr_t0 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    dspm::TrAcc tr_acc;
+    for (int i = 0; i < 16; i++) tr_acc.acc[i] = 0;
+    tr_acc.last = tr_t0;
+#ifdef DSP_TRACE_STAMPS
+    dspm::TrAcc *trp = &tr_acc;          // segment stamps: a third build, slower than the real kernel
+#else
+    dspm::TrAcc *trp = nullptr;
+#endif
+#else
+    dspm::TrAcc *trp = nullptr;
+#endif
 
     if (role == 0) {
         // =================== timing wave ===================
@@ -473,30 +541,41 @@ __global__ __launch_bounds__(128) void sync_split_kernel(SyncParams P)
             if (o_rec) st_cplx(o_rec + obase, r0.re, r0.im);
         }
         bool overflow = false;
-        const int m = T / TQ;                 // queue blocks per DMA block
-        int it = 0;
-        for (int qb = 0;; qb++) {
-            if (ring && (qb % m) == 0) tl.advance(qb / m, sps, T, P.C, P.nwait);
-            const int buf = qb & 1;
-            for (int t = 0; t < TQ; t++, it++) {
+        // DMA blocks (T iterations) and queue blocks (TQ iterations) tick independently
+        int it = 0, tq = 0, buf = 0;
+        bool more = true;
+        for (int blk = 0; more; blk++) {
+            if (prio_n && --prio_c == 0) { prio_c = prio_n; rotate_priority(slot, ++prio_ph); }
+            DSP_TR(trp, 0);
+            if (ring) tl.advance(blk, sps, T, P.C, P.nwait);
+            DSP_TR(trp, 9);
+            for (int t = 0; t < T; t++, it++) {
                 const int rec_row = it + ROFF;
                 if (gs.active && rec_row >= cap_rows) { gs.active = false; overflow = true; }
-                dspm::GOut go = timing_iter<IN, VARIANT, false, SC>(tl, gs, tc, nullptr);
+                DSP_TR(trp, 0);
+                dspm::GOut go = timing_iter<IN, VARIANT, false, SC>(tl, gs, tc, nullptr, trp);
+                DSP_TR(trp, 5);
                 const int rrow = rec_row < cap_rows ? rec_row : cap_rows;
                 const int erow = it < cap_rows ? it : cap_rows;
                 const size_t g_off = obase + (size_t)erow * 64;
                 if (o_rec) st_cplx(o_rec + obase + (size_t)rrow * 64, go.rec.re, go.rec.im, go.produced);
                 if (o_terr) st_val(o_terr + g_off, go.err, go.produced);
                 if (o_mu) st_val(o_mu + g_off, go.mu, go.produced);
+                DSP_TR(trp, 6);
                 d2v qv = {go.rec.re, go.rec.im};
-                q_data[(buf * TQ + t) * 64 + lane] = qv;
-                q_flag[(buf * TQ + t) * 64 + lane] = go.produced ? 1 : 0;
+                q_data[(buf * TQ + tq) * 64 + lane] = qv;
+                q_flag[(buf * TQ + tq) * 64 + lane] = go.produced ? 1 : 0;
                 n_rec += go.produced ? 1 : 0;
+                DSP_TR(trp, 7);
+                if (++tq == TQ) {                      // hand the queue block over (uniform)
+                    more = __any(gs.active);
+                    if (lane == 0) q_more[buf] = more ? 1 : 0;
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    DSP_TR(trp, 8);
+                    tq = 0; buf ^= 1;
+                    if (!more) break;
+                }
             }
-            const bool more = __any(gs.active);
-            if (lane == 0) q_more[buf] = more ? 1 : 0;
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (!more) break;
         }
         if (lane_ok) {
             if (P.n_out) P.n_out[b] = n_rec;
@@ -525,28 +604,47 @@ __global__ __launch_bounds__(128) void sync_split_kernel(SyncParams P)
             if (o_dec) st_b8(o_dec + obase, fo.quad);
         }
         int it = 0;
+        prio_n = prio_n ? (prio_n * T / TQ > 0 ? prio_n * T / TQ : 1) : 0;     // same period in queue blocks
+        prio_c = 1;
         for (int qb = 0;; qb++) {
             const int buf = qb & 1;
+            if (prio_n && --prio_c == 0) { prio_c = prio_n; rotate_priority(slot, ++prio_ph); }
+            DSP_TR(trp, 5);
             asm volatile("s_barrier" ::: "memory");
+            DSP_TR(trp, 0);
             const int more = q_more[buf];
             for (int t = 0; t < TQ; t++, it++) {
                 const int row = it + ROFF;
                 d2v qv = q_data[(buf * TQ + t) * 64 + lane];
                 const bool pend = q_flag[(buf * TQ + t) * 64 + lane] != 0;
                 cd x; x.re = qv.x; x.im = qv.y;
+                DSP_TR(trp, 1);
                 if (row < cap_rows) {                                    // uniform
-                    FllLane fo = fll_iter(MK, pend, x, (double)row + i0, freq, integ, kp, ki);
+                    FllLane fo = fll_iter(MK, pend, x, (double)row + i0, freq, integ, kp, ki, trp);
                     const size_t off = obase + (size_t)row * 64;
                     if (o_sig) st_cplx(o_sig + off, fo.sr, fo.si);
                     if (o_freq) st_val(o_freq + off, fo.freq);
                     if (o_ef) st_val(o_ef + off, fo.ef);
                     if (o_dec) st_b8(o_dec + off, fo.quad);
                 }
+                DSP_TR(trp, 5);
             }
             if (!more) break;
         }
         if (lane_ok && P.fll_out) { P.fll_out[2 * b] = freq; P.fll_out[2 * b + 1] = integ; }
     }
+#ifdef DSP_TRACE
+    if (P.trace) {
+        const unsigned long long tr_t1 = __builtin_amdgcn_s_memtime();
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+        if (lane == 0) {
+            unsigned long long *t = P.trace + ((size_t)tile * 2 + role) * 20;
+            t[0] = tr_t0; t[1] = tr_t1; t[2] = hw; t[3] = xcc;
+            for (int i = 0; i < 16; i++) t[4 + i] = tr_acc.acc[i];
+        }
+    }
+#endif
 }
 
 }  // namespace

@@ -49,7 +49,7 @@ void dsp_destroy(dsp_ctx *ctx);
 const char *dsp_last_error(void);
 int dsp_set_stream(dsp_ctx *ctx, void *hip_stream);      /* adopt an external hipStream_t */
 int dsp_synchronize(dsp_ctx *ctx);
-int dsp_set_option(dsp_ctx *ctx, const char *name, int64_t value); /* "ring_rows", "lds_pad", "split" */
+int dsp_set_option(dsp_ctx *ctx, const char *name, int64_t value); /* "ring_rows", "lds_pad", "split", "queue_block" */
 
 /* ---- device memory and timing (for *_dev pipelines and bench.py) ---------- */
 int dsp_malloc(dsp_ctx *ctx, size_t bytes, void **dptr);

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-wave start/end stamps of the split recurrence kernel (trace build only).
+
+    make -C dsp_amd/csrc trace
+    DSP_HIP_LIB=dsp_amd/libdsp_hip_trace.so python tools/wave_timeline.py [bursts]
+
+Prints how the tiles were spread over XCDs / CUs / SIMDs and how long the waves lived,
+which is what decides whether a launch is balanced.  Never used by the product path.
+"""
+import collections
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dsp_amd                                               # noqa: E402
+from dsp_amd.pipeline import BurstPipeline                   # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+ctx = dsp_amd.Context(0)
+pipe = BurstPipeline(ctx, B, 2048, 4)
+pipe.generate()
+pipe.matched_filter(free_raw=True)
+nt = pipe.ntiles
+d_tr = ctx.malloc(nt * 2 * 20 * 8)
+ctx.memset(d_tr, 0, nt * 2 * 20 * 8)
+ctx.set_option("trace_ptr", d_tr)
+for opt in ("prio_period", "queue_block", "ring_rows", "trace_stamps", "split"):
+    if os.environ.get(opt.upper()):
+        ctx.set_option(opt, int(os.environ[opt.upper()]))
+for _ in range(3):
+    pipe.run()
+ctx.synchronize()
+ctx.timer_start()
+pipe.run()
+ms = ctx.timer_stop()
+tr = np.empty((nt, 2, 20), np.uint64)
+ctx.d2h(tr, d_tr)
+t0 = tr[..., 0].astype(np.int64)
+t1 = tr[..., 1].astype(np.int64)
+hw = tr[..., 2].astype(np.int64)
+xcc = tr[..., 3].astype(np.int64) & 0xF
+# HW_ID (gfx9): wave[3:0] simd[5:4] pipe[7:6] cu[11:8] sh[12] se[15:13] (se is 3 bits on gfx94x)
+simd = (hw >> 4) & 3
+cu = (hw >> 8) & 0xF
+sh = (hw >> 12) & 1
+se = (hw >> 13) & 7
+print(f"B={B} tiles={nt} kernel {ms:.3f} ms")
+base = t0.min()
+life = (t1 - t0)
+print("wave lifetime cycles  G: min %d med %d max %d   F: min %d med %d max %d" % (
+    life[:, 0].min(), np.median(life[:, 0]), life[:, 0].max(),
+    life[:, 1].min(), np.median(life[:, 1]), life[:, 1].max()))
+q = [0, 5, 25, 50, 75, 95, 100]
+print("lifetime percentiles", q, np.percentile(life, q).astype(np.int64).tolist())
+# (the s_memtime counters of different CUs are not synchronised: only differences inside a wave)
+cuid = xcc[:, 0] * 1000 + se[:, 0] * 100 + sh[:, 0] * 16 + cu[:, 0]
+cnt = collections.Counter(cuid.tolist())
+print("CUs used:", len(cnt), " tiles per CU histogram:", sorted(collections.Counter(cnt.values()).items()))
+same = (simd[:, 0] == simd[:, 1]).mean()
+print(f"G and F wave of a tile on the same SIMD: {same * 100:.1f}%")
+sc = collections.Counter((cuid * 4 + simd[:, 0]).tolist())
+sc.update((cuid * 4 + simd[:, 1]).tolist())
+print("waves per SIMD histogram:", sorted(collections.Counter(sc.values()).items()))
+# lifetime as a function of how many tiles shared the CU
+for n in sorted(set(cnt.values())):
+    m = np.array([cnt[c] == n for c in cuid.tolist()])
+    print(f"  CUs with {n} tiles: median wave life {int(np.median(life[m]))} cycles")
+if os.environ.get("TRACE_STAMPS"):
+    # segment sums (ticks) per wave, averaged over the tiles, per symbol
+    seg = tr[..., 4:].astype(np.float64).mean(axis=0) / 2048.0
+    names_g = ["loop/advance overhead", "index+vote", "LDS reads a,b,c", "lerp+TED+mu+out index", "LDS reads out",
+               "out lerp + commit", "cvt + stores", "queue write", "barrier", "DMA wait+issue"]
+    names_f = ["barrier -> more flag", "queue read", "phase+sincos", "rotate+sign+vote", "atan2", "PI + stores + loop"]
+    print("G wave, ticks per symbol (total %.0f):" % seg[0].sum())
+    for i, n in enumerate(names_g):
+        print(f"   {n:26s} {seg[0, i]:8.1f}  {100 * seg[0, i] / seg[0].sum():5.1f}%")
+    print("F wave, ticks per symbol (total %.0f):" % seg[1].sum())
+    for i, n in enumerate(names_f):
+        print(f"   {n:26s} {seg[1, i]:8.1f}  {100 * seg[1, i] / seg[1].sum():5.1f}%")
+ctx.free(d_tr)
+pipe.close()
+ctx.close()
