@@ -80,6 +80,28 @@ __device__ __forceinline__ void st_cplx(d2v *p, double re, double im, bool keep 
     asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(p), "v"(v) : "memory");
 }
 
+// stores through a wave-uniform base (SGPR pair) + 32-bit lane offset: no 64-bit VALU address math
+__device__ __forceinline__ void sst(const void *base, unsigned voff, float v)
+{
+    asm volatile("global_store_dword %0, %1, %2" :: "v"(voff), "v"(v), "s"(base) : "memory");
+}
+__device__ __forceinline__ void sst(const void *base, unsigned voff, double v)
+{
+    asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(voff), "v"(v), "s"(base) : "memory");
+}
+__device__ __forceinline__ void sst(const void *base, unsigned voff, f2v v)
+{
+    asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(voff), "v"(v), "s"(base) : "memory");
+}
+__device__ __forceinline__ void sst(const void *base, unsigned voff, d2v v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(voff), "v"(v), "s"(base) : "memory");
+}
+__device__ __forceinline__ void sst_b8(const void *base, unsigned voff, unsigned v)
+{
+    asm volatile("global_store_byte %0, %1, %2" :: "v"(voff), "v"(v), "s"(base) : "memory");
+}
+
 #define WCASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
 __device__ __forceinline__ void wait_vmcnt(int n)
 {
@@ -292,6 +314,47 @@ __device__ __forceinline__ dspm::GOut timing_iter(const Tile<IN> &tl, dspm::GSta
             go = dspm::ted_iter(gs, len, sps, tc.n_symbols, alpha, Lp, FetchFn<IN>{tl});
     }
     return go;
+}
+
+// Steady-state gardner2.py iteration: every lane of the wave is active, the ring window is
+// past the burst start (win_lo > 0, so idx_early >= 1) and ends at least 2*sps + 1 rows before
+// the shortest burst's end (so k <= len - sps and idx_late + 1 < len hold for every lane), and
+// the caller has checked the output capacity for the whole block.  What remains per lane is
+// the wrap test on mu and the window test on the rows; one vote, then straight-line code with
+// no per-lane commit selects.  Returns false (state untouched) when a lane fails the vote.
+template <typename IN, bool SC>
+__device__ __forceinline__ bool g2_steady(const Tile<IN> &tl, dspm::GState &gs, const TimingConst &tc,
+                                          cd &rec, double &err)
+{
+    const double mu = gs.mu, spsd = tc.spsd;
+    const double kd = (double)gs.k;
+    const double i_a = (kd - spsd) + mu;                 // gardner2.py:76-78
+    const double i_b = (kd - tc.halfd) + mu;
+    const double i_c = kd + mu;
+    const int r_a = __double2int_rz(i_a), r_b = __double2int_rz(i_b), r_c = __double2int_rz(i_c);
+    const bool in = (mu < spsd) & (mu >= -spsd) & (r_a >= tl.win_lo) & (r_c + 1 < tl.win_hi);
+    if (!__all(in)) return false;
+    const cd a0 = tl.template lds_at<SC>(r_a), a1 = tl.template lds_at<SC>(r_a + 1);
+    const cd b0 = tl.template lds_at<SC>(r_b), b1 = tl.template lds_at<SC>(r_b + 1);
+    const cd c0 = tl.template lds_at<SC>(r_c), c1 = tl.template lds_at<SC>(r_c + 1);
+    const cd xa = dspm::lerp(a0, a1, dspm::fract_pos(i_a));
+    const cd xb = dspm::lerp(b0, b1, dspm::fract_pos(i_b));
+    const cd xc = dspm::lerp(c0, c1, dspm::fract_pos(i_c));
+    const double e = dspm::ted_error(xa, xb, xc);        // :87
+    const double mu_n = mu - tc.alpha * e;               // :91
+    const double i_o = kd + mu_n;                        // :95
+    const int r_o = __double2int_rz(i_o);
+    if (__all(r_o == r_c)) {                             // i_o in [r_c, r_c + 1): samples in registers
+        rec = dspm::lerp(c0, c1, dspm::fract_pos(i_o));
+    } else if (__all((i_o > 0.0) & (i_o < 1.0e9) & (r_o >= tl.win_lo) & (r_o + 1 < tl.win_hi))) {
+        rec = dspm::lerp(tl.template lds_at<SC>(r_o), tl.template lds_at<SC>(r_o + 1), dspm::fract_pos(i_o));
+    } else {
+        rec = dspm::g2_interp(i_o, tc.len, (const dspm::LagrangeW *)nullptr, FetchFn<IN>{tl});
+    }
+    err = e;
+    gs.mu = mu_n;
+    gs.k += tc.sps;                                      // :98
+    return true;
 }
 
 // FLL step for every lane, committed by select (no divergent control flow)
@@ -541,6 +604,17 @@ __global__ __launch_bounds__(128) void sync_split_kernel(SyncParams P)
             if (o_rec) st_cplx(o_rec + obase, r0.re, r0.im);
         }
         bool overflow = false;
+        // wave-uniform facts for the steady-state path
+        int min_len = len;
+        for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(min_len, d); min_len = o < min_len ? o : min_len; }
+        min_len = __builtin_amdgcn_readfirstlane(min_len);
+        const bool steady_ok = VARIANT == DSP_VARIANT_GARDNER2 && ring && o_rec && o_terr && o_mu;
+        bool all_active = __all(gs.active);
+        const unsigned char *rec_t = (const unsigned char *)(o_rec + (size_t)tile * out_rows * 64);
+        const unsigned char *err_t = (const unsigned char *)(o_terr + (size_t)tile * out_rows * 64);
+        const unsigned char *mu_t = (const unsigned char *)(o_mu + (size_t)tile * out_rows * 64);
+        const unsigned lane_s = lane * (unsigned)sizeof(OS), lane_c = lane * (unsigned)sizeof(OC);
+        int n_steady = 0;
         // DMA blocks (T iterations) and queue blocks (TQ iterations) tick independently
         int it = 0, tq = 0, buf = 0;
         bool more = true;
@@ -549,23 +623,47 @@ __global__ __launch_bounds__(128) void sync_split_kernel(SyncParams P)
             DSP_TR(trp, 0);
             if (ring) tl.advance(blk, sps, T, P.C, P.nwait);
             DSP_TR(trp, 9);
+            bool steady = steady_ok && all_active && tl.win_lo > 0 && tl.win_hi + 2 * sps + 1 <= min_len &&
+                          it + T + ROFF < cap_rows;
             for (int t = 0; t < T; t++, it++) {
-                const int rec_row = it + ROFF;
-                if (gs.active && rec_row >= cap_rows) { gs.active = false; overflow = true; }
                 DSP_TR(trp, 0);
-                dspm::GOut go = timing_iter<IN, VARIANT, false, SC>(tl, gs, tc, nullptr, trp);
-                DSP_TR(trp, 5);
-                const int rrow = rec_row < cap_rows ? rec_row : cap_rows;
-                const int erow = it < cap_rows ? it : cap_rows;
-                const size_t g_off = obase + (size_t)erow * 64;
-                if (o_rec) st_cplx(o_rec + obase + (size_t)rrow * 64, go.rec.re, go.rec.im, go.produced);
-                if (o_terr) st_val(o_terr + g_off, go.err, go.produced);
-                if (o_mu) st_val(o_mu + g_off, go.mu, go.produced);
-                DSP_TR(trp, 6);
-                d2v qv = {go.rec.re, go.rec.im};
-                q_data[(buf * TQ + tq) * 64 + lane] = qv;
-                q_flag[(buf * TQ + tq) * 64 + lane] = go.produced ? 1 : 0;
-                n_rec += go.produced ? 1 : 0;
+                bool done = false;
+                if (steady) {
+                    cd rec; double e;
+                    done = g2_steady<IN, SC>(tl, gs, tc, rec, e);
+                    if (done) {
+                        DSP_TR(trp, 5);
+                        const unsigned row_s = (unsigned)it * 64u * (unsigned)sizeof(OS);
+                        const unsigned row_c = (unsigned)(it + ROFF) * 64u * (unsigned)sizeof(OC);
+                        OC rv = {(OS)rec.re, (OS)rec.im};
+                        sst(rec_t, lane_c + row_c, rv);
+                        sst(err_t, lane_s + row_s, (OS)e);
+                        sst(mu_t, lane_s + row_s, (OS)gs.mu);
+                        DSP_TR(trp, 6);
+                        d2v qv = {rec.re, rec.im};
+                        q_data[(buf * TQ + tq) * 64 + lane] = qv;
+                        q_flag[(buf * TQ + tq) * 64 + lane] = 1;
+                        n_steady++;
+                    }
+                }
+                if (!done) {
+                    const int rec_row = it + ROFF;
+                    if (gs.active && rec_row >= cap_rows) { gs.active = false; overflow = true; }
+                    dspm::GOut go = timing_iter<IN, VARIANT, false, SC>(tl, gs, tc, nullptr, trp);
+                    DSP_TR(trp, 5);
+                    const int rrow = rec_row < cap_rows ? rec_row : cap_rows;
+                    const int erow = it < cap_rows ? it : cap_rows;
+                    const size_t g_off = obase + (size_t)erow * 64;
+                    if (o_rec) st_cplx(o_rec + obase + (size_t)rrow * 64, go.rec.re, go.rec.im, go.produced);
+                    if (o_terr) st_val(o_terr + g_off, go.err, go.produced);
+                    if (o_mu) st_val(o_mu + g_off, go.mu, go.produced);
+                    DSP_TR(trp, 6);
+                    d2v qv = {go.rec.re, go.rec.im};
+                    q_data[(buf * TQ + tq) * 64 + lane] = qv;
+                    q_flag[(buf * TQ + tq) * 64 + lane] = go.produced ? 1 : 0;
+                    n_rec += go.produced ? 1 : 0;
+                    if (steady) steady = __all(gs.active);
+                }
                 DSP_TR(trp, 7);
                 if (++tq == TQ) {                      // hand the queue block over (uniform)
                     more = __any(gs.active);
@@ -576,7 +674,9 @@ __global__ __launch_bounds__(128) void sync_split_kernel(SyncParams P)
                     if (!more) break;
                 }
             }
+            all_active = __all(gs.active);
         }
+        n_rec += n_steady;
         if (lane_ok) {
             if (P.n_out) P.n_out[b] = n_rec;
             if (P.status) P.status[b] = overflow ? 1 : 0;
