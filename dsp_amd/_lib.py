@@ -53,6 +53,18 @@ class FirArgs(C.Structure):
     ]
 
 
+class CaptureArgs(C.Structure):
+    """struct dsp_capture_args of include/dsp_hip.h"""
+    _fields_ = [
+        ("x", C.c_void_p), ("in_kind", C.c_int32), ("normalize", C.c_int32), ("n_samples", C.c_int64),
+        ("h", C.c_void_p), ("n_taps", C.c_int32), ("sps", C.c_int32),
+        ("alpha", C.c_double), ("mu0", C.c_double), ("Bn", C.c_double), ("y", C.c_double),
+        ("seg_len", C.c_int64), ("warmup", C.c_int64),
+        ("dec", C.c_void_p), ("mu", C.c_void_p), ("freq", C.c_void_p),
+        ("capacity", C.c_int64), ("n_symbols", C.c_void_p), ("seg_info", C.c_void_p),
+    ]
+
+
 _lib = None
 _lock = threading.Lock()
 
@@ -121,12 +133,17 @@ def _declare(L):
     L.dsp_fir_workspace_bytes.restype = i64
     L.dsp_fir_tiles_dev.argtypes = [vp, C.POINTER(FirArgs)]
     L.dsp_synth_bursts_dev.argtypes = [vp, C.c_uint64, i64, i64, ci, ci, vp, ci, dbl, vp]
+    L.dsp_sync_capture_segmented.argtypes = [vp, C.POINTER(CaptureArgs)]
+    L.dsp_sync_capture_segmented_dev.argtypes = [vp, C.POINTER(CaptureArgs)]
+    L.dsp_capture_segments.argtypes = [i64, i64]
+    L.dsp_capture_segments.restype = i64
     for name in ("dsp_device_count", "dsp_create", "dsp_set_stream", "dsp_synchronize",
                  "dsp_set_option", "dsp_malloc", "dsp_free", "dsp_memset", "dsp_h2d", "dsp_d2h",
                  "dsp_timer_start", "dsp_timer_stop", "dsp_rrc_taps", "dsp_fll_gains",
                  "dsp_gardner", "dsp_fll", "dsp_sync_chain", "dsp_tile_bursts_dev",
                  "dsp_untile_dev", "dsp_sync_tiles_dev", "dsp_load_iq_i16", "dsp_load_iq_f32",
-                 "dsp_fir_same_std", "dsp_rx_chain", "dsp_fir_tiles_dev", "dsp_synth_bursts_dev"):
+                 "dsp_fir_same_std", "dsp_rx_chain", "dsp_fir_tiles_dev", "dsp_synth_bursts_dev",
+                 "dsp_sync_capture_segmented", "dsp_sync_capture_segmented_dev"):
         getattr(L, name).restype = ci
 
 

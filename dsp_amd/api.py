@@ -329,3 +329,60 @@ def rx_chain_batch(x, taps, sps=4, alpha=0.007, mu_initial=0.0, Bn=0.03, y=1, *,
     bufs["n_out"] = n_out
     bufs["std"] = std
     return bufs
+
+
+def sync_capture_segmented(x, sps=4, alpha=0.007, mu_initial=0.0, Bn=0.003, y=1, *, taps=None,
+                           seg_len=65536, warmup=4096, normalize=True, want=("dec", "mu", "freq"),
+                           ctx=None):
+    """Segment-parallel Gardner + FLL + decisions over ONE long capture (no reference
+    counterpart; north-star (c), include/dsp_hip.h dsp_sync_capture_segmented).
+
+    x: 1-D complex64 samples, or 1-D int16 interleaved I,Q words (read_iq_int16 semantics,
+    hw1/gardner.py:77-91).  taps: matched filter applied as np.convolve(x, taps, 'same') /
+    np.std over the whole capture (worker.py:173-178), None when x is already filtered.
+    Returns a dict: dec uint8[n] quadrant indices, mu / freq float32[n] if wanted,
+    seg_info int32[S, 4] = (first kept row, end row, rotation, rows produced) per segment.
+    """
+    ctx = ctx or default_context()
+    x = np.asarray(x)
+    if x.ndim != 1:
+        raise ValueError("one capture = one 1-D array")
+    if x.dtype == np.int16:
+        n = x.size // 2
+        x = np.ascontiguousarray(x[:2 * n])
+        kind = DSP_I16
+    else:
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        n = x.size
+        kind = DSP_C64
+    if n == 0:
+        raise IndexError("empty capture")                     # gardner2.py:59
+    S = int(_lib.lib().dsp_capture_segments(n, int(seg_len)))
+    cap = n // sps + 8 * max(S, 1) + 64
+    dec = np.zeros(cap, np.uint8)
+    mu = np.zeros(cap, np.float32) if "mu" in want else None
+    freq = np.zeros(cap, np.float32) if "freq" in want else None
+    info = np.zeros((max(S, 1), 4), np.int32)
+    total = C.c_int64(0)
+    a = _lib.CaptureArgs()
+    a.x = x.ctypes.data; a.in_kind = kind; a.normalize = 1 if normalize else 0; a.n_samples = n
+    h = None
+    if taps is not None:
+        h = np.ascontiguousarray(taps, dtype=np.float64)
+        a.h = h.ctypes.data; a.n_taps = h.size
+    a.sps = int(sps); a.alpha = float(alpha); a.mu0 = float(mu_initial); a.Bn = float(Bn); a.y = float(y)
+    a.seg_len = int(seg_len); a.warmup = int(warmup)
+    a.dec = dec.ctypes.data
+    a.mu = mu.ctypes.data if mu is not None else None
+    a.freq = freq.ctypes.data if freq is not None else None
+    a.capacity = cap
+    a.n_symbols = C.addressof(total)
+    a.seg_info = info.ctypes.data
+    check(_lib.lib().dsp_sync_capture_segmented(ctx.handle, C.byref(a)))
+    nn = int(total.value)
+    out = {"n": nn, "dec": dec[:nn], "seg_info": info[:S]}
+    if mu is not None:
+        out["mu"] = mu[:nn]
+    if freq is not None:
+        out["freq"] = freq[:nn]
+    return out

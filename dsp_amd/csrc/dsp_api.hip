@@ -758,6 +758,165 @@ int dsp_rx_chain(dsp_ctx *c, const void *x, int in_kind, int64_t B, int64_t N, i
                         ef, dec, n_out, out_stride);
 }
 
+// ---------------------------------------------------------------------------
+// Segment-parallel mode (segment_kernels.hip)
+int64_t dsp_capture_segments(int64_t n_samples, int64_t seg_len)
+{
+    if (n_samples <= 0 || seg_len <= 0) return 0;
+    return (n_samples + seg_len - 1) / seg_len;
+}
+
+int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
+{
+    if (!c || !a) return fail(DSP_E_ARG, "ctx/args is NULL");
+    if (!a->x || !a->dec) return fail(DSP_E_ARG, "capture: x / dec is NULL");
+    if (a->in_kind != DSP_I16 && a->in_kind != DSP_C64) return fail(DSP_E_ARG, "capture: in_kind must be DSP_I16 or DSP_C64");
+    if (a->sps < 1 || a->sps > 64) return fail(DSP_E_ARG, "capture: sps out of range");
+    if (a->n_samples < 2 * a->sps) return fail(DSP_E_ARG, "capture: too few samples");
+    if (a->seg_len < 16 * a->sps || a->seg_len % a->sps) return fail(DSP_E_ARG, "capture: seg_len must be a multiple of sps, >= 16 symbols");
+    if (a->warmup < 0) return fail(DSP_E_ARG, "capture: negative warm-up");
+    if (a->h && (a->n_taps < 1 || a->n_taps > 4096)) return fail(DSP_E_ARG, "capture: bad n_taps");
+    if (!(a->y > 0.0)) return fail(DSP_E_ARG, "capture: y must be > 0");
+    const int64_t n = a->n_samples, seg = a->seg_len;
+    const int64_t S64 = dsp_capture_segments(n, seg);
+    if (S64 > (1 << 24)) return fail(DSP_E_ARG, "capture: too many segments");
+    const int S = (int)S64, sps = a->sps;
+    const int64_t lead = a->warmup * sps, tail = 4 * (int64_t)sps + 8;
+    const int64_t Nw = seg + lead + tail;                  // longest window
+    if (Nw >= (1LL << 30)) return fail(DSP_E_ARG, "capture: window too long");
+    const int64_t rows = dsp_tile_rows(Nw), out_rows = Nw / sps + 8, ntiles = (S + 63) / 64;
+    hipStream_t st = c->stream;
+    HIP_TRY(hipSetDevice(c->device));
+
+    DevBuf d_starts, d_lens, d_tiles, d_mu, d_dec, d_freq, d_nout, d_status, d_j0, d_j1, d_rot, d_pl, d_off;
+    HIP_TRY(d_starts.alloc((size_t)S * 8)); HIP_TRY(d_lens.alloc((size_t)S * 4));
+    HIP_TRY(d_tiles.alloc((size_t)ntiles * rows * 64 * 8));
+    HIP_TRY(d_mu.alloc((size_t)ntiles * out_rows * 64 * 4));
+    HIP_TRY(d_dec.alloc((size_t)ntiles * out_rows * 64));
+    if (a->freq) HIP_TRY(d_freq.alloc((size_t)ntiles * out_rows * 64 * 4));
+    HIP_TRY(d_nout.alloc((size_t)S * 4)); HIP_TRY(d_status.alloc((size_t)S * 4));
+    HIP_TRY(d_j0.alloc((size_t)S * 4)); HIP_TRY(d_j1.alloc((size_t)S * 4)); HIP_TRY(d_rot.alloc((size_t)S * 4));
+    HIP_TRY(d_pl.alloc((size_t)S * 8)); HIP_TRY(d_off.alloc((size_t)(S + 1) * 8));
+    HIP_TRY(hipMemsetAsync(d_tiles.p, 0, (size_t)ntiles * rows * 64 * 8, st));
+
+    // ---- windows -> tiles (optionally through the matched filter) ------------------------
+    DevBuf d_peak, d_c64, d_ws, d_inv, d_starts0, d_lens0;
+    const float *in_scale = nullptr;
+    if (a->in_kind == DSP_I16) {
+        HIP_TRY(d_peak.alloc(16));
+        if (!a->h) HIP_TRY(d_c64.alloc((size_t)n * 8));
+        HIP_TRY(launch_iq_i16(a->x, n, a->normalize, d_peak.as<unsigned>(), d_peak.as<float>() + 1,
+                              a->h ? nullptr : d_c64.p, st));
+        in_scale = d_peak.as<float>() + 1;
+    }
+    HIP_TRY(launch_seg_windows(S, n, seg, lead, tail, d_starts.as<int64_t>(), d_lens.as<int>(), st));
+    if (a->h) {
+        // pass 1: statistics of the whole filtered stream over the non-overlapping partition
+        HIP_TRY(d_starts0.alloc((size_t)S * 8)); HIP_TRY(d_lens0.alloc((size_t)S * 4));
+        HIP_TRY(launch_seg_windows(S, n, seg, 0, 0, d_starts0.as<int64_t>(), d_lens0.as<int>(), st));
+        FirParams P;
+        memset(&P, 0, sizeof(P));
+        if (!fir_plan(a->in_kind, a->n_taps, (int)seg, P))
+            return fail(DSP_E_ARG, "capture: %d taps are too many for the LDS-tiled filter", a->n_taps);
+        HIP_TRY(d_ws.alloc((size_t)S * P.nchunk * 32));
+        HIP_TRY(d_inv.alloc((size_t)S * 8));
+        P.src = a->x; P.starts = d_starts0.as<int64_t>(); P.n_total = n; P.lens = d_lens0.as<int>();
+        P.len_all = (int)seg; P.B = S; P.h = a->h; P.M = a->n_taps; P.start = (a->n_taps - 1) / 2;
+        P.in_scale = in_scale; P.dst = nullptr; P.rows = (int)rows; P.stats = d_ws.as<double>();
+        HIP_TRY(launch_fir_tile(P, a->in_kind, st));
+        HIP_TRY(launch_fir_stats_global(P.stats, (int64_t)S * P.nchunk, S, nullptr, d_inv.as<double>(), st));
+        // pass 2: the overlapping windows, scaled by 1/std, one rounding into complex64
+        FirParams Q;
+        memset(&Q, 0, sizeof(Q));
+        if (!fir_plan(a->in_kind, a->n_taps, (int)Nw, Q)) return fail(DSP_E_ARG, "capture: filter plan failed");
+        Q.src = a->x; Q.starts = d_starts.as<int64_t>(); Q.n_total = n; Q.lens = d_lens.as<int>();
+        Q.len_all = (int)Nw; Q.B = S; Q.h = a->h; Q.M = a->n_taps; Q.start = (a->n_taps - 1) / 2;
+        Q.in_scale = in_scale; Q.dst = d_tiles.p; Q.rows = (int)rows; Q.scale = d_inv.as<double>();
+        HIP_TRY(launch_fir_tile(Q, a->in_kind, st));
+    } else {
+        const void *src = a->in_kind == DSP_I16 ? d_c64.p : a->x;
+        HIP_TRY(launch_tile_from_bursts(src, 0, d_lens.as<int>(), (int)Nw, S, d_tiles.p, (int)rows, 8, st,
+                                        d_starts.as<int64_t>()));
+    }
+
+    // ---- the batched recurrence over the windows -------------------------------------------
+    dsp_sync_args sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.x = d_tiles.p; sa.dtype = DSP_C64; sa.variant = DSP_GARDNER2; sa.B = S; sa.N = Nw; sa.in_rows = rows;
+    sa.lens = d_lens.as<int32_t>(); sa.sps = sps; sa.alpha = a->alpha; sa.mu0 = a->mu0; sa.do_fll = 1;
+    sa.Bn = a->Bn; sa.y = a->y; sa.mu = d_mu.p; sa.dec = d_dec.as<uint8_t>(); sa.freq = a->freq ? d_freq.p : nullptr;
+    sa.out_rows = out_rows; sa.n_out = d_nout.as<int32_t>(); sa.status = d_status.as<int32_t>();
+    {
+        int rc = dsp_sync_tiles_dev(c, &sa);
+        if (rc != DSP_OK) return rc;
+    }
+
+    // ---- stitch ----------------------------------------------------------------------------
+    SegParams G;
+    memset(&G, 0, sizeof(G));
+    G.S = S; G.sps = sps; G.out_rows = (int)out_rows; G.n_total = n; G.seg_len = seg;
+    G.starts = d_starts.as<int64_t>(); G.n_out = d_nout.as<int>(); G.mu = d_mu.p; G.dec = d_dec.as<uint8_t>();
+    G.freq = a->freq ? d_freq.p : nullptr;
+    G.j0 = d_j0.as<int>(); G.j1 = d_j1.as<int>(); G.p_last = d_pl.as<double>(); G.rot = d_rot.as<int>();
+    G.off = d_off.as<int64_t>();
+    int vote = (int)(a->warmup / 2);
+    if (vote > 256) vote = 256;
+    HIP_TRY(launch_seg_stitch(G, vote, st));
+    HIP_TRY(launch_seg_gather(G, a->dec, a->mu, a->freq, a->capacity, st));
+    int64_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, d_off.as<int64_t>() + S, 8, hipMemcpyDeviceToHost, st));
+    if (a->seg_info) {
+        std::vector<int32_t> j0(S), j1(S), rot(S), no(S);
+        HIP_TRY(hipMemcpyAsync(j0.data(), d_j0.p, (size_t)S * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(j1.data(), d_j1.p, (size_t)S * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(rot.data(), d_rot.p, (size_t)S * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(no.data(), d_nout.p, (size_t)S * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (int s = 0; s < S; s++) {
+            a->seg_info[4 * s] = j0[s]; a->seg_info[4 * s + 1] = j1[s];
+            a->seg_info[4 * s + 2] = rot[s]; a->seg_info[4 * s + 3] = no[s];
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    if (a->n_symbols) *a->n_symbols = total;
+    if (total > a->capacity)
+        return fail(DSP_E_CAPACITY, "capture: %lld symbols, capacity %lld", (long long)total, (long long)a->capacity);
+    return DSP_OK;
+}
+
+int dsp_sync_capture_segmented(dsp_ctx *c, const dsp_capture_args *a)
+{
+    if (!c || !a) return fail(DSP_E_ARG, "ctx/args is NULL");
+    if (!a->x || !a->dec || a->n_samples <= 0 || a->capacity <= 0) return fail(DSP_E_ARG, "capture: bad arguments");
+    if (a->in_kind != DSP_I16 && a->in_kind != DSP_C64) return fail(DSP_E_ARG, "capture: in_kind must be DSP_I16 or DSP_C64");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t ie = a->in_kind == DSP_I16 ? 4 : 8;
+    DevBuf d_x, d_h, d_dec, d_mu, d_freq;
+    HIP_TRY(d_x.alloc((size_t)a->n_samples * ie));
+    HIP_TRY(hipMemcpyAsync(d_x.p, a->x, (size_t)a->n_samples * ie, hipMemcpyHostToDevice, c->stream));
+    dsp_capture_args d = *a;
+    d.x = d_x.p;
+    if (a->h) {
+        if (a->n_taps < 1) return fail(DSP_E_ARG, "capture: bad n_taps");
+        HIP_TRY(d_h.alloc((size_t)a->n_taps * 8));
+        HIP_TRY(hipMemcpyAsync(d_h.p, a->h, (size_t)a->n_taps * 8, hipMemcpyHostToDevice, c->stream));
+        d.h = d_h.as<double>();
+    }
+    HIP_TRY(d_dec.alloc((size_t)a->capacity)); d.dec = d_dec.as<uint8_t>();
+    if (a->mu) { HIP_TRY(d_mu.alloc((size_t)a->capacity * 4)); d.mu = d_mu.as<float>(); }
+    if (a->freq) { HIP_TRY(d_freq.alloc((size_t)a->capacity * 4)); d.freq = d_freq.as<float>(); }
+    int64_t total = 0;
+    d.n_symbols = &total;
+    int rc = dsp_sync_capture_segmented_dev(c, &d);
+    if (a->n_symbols) *a->n_symbols = total;
+    if (rc != DSP_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(a->dec, d_dec.p, (size_t)total, hipMemcpyDeviceToHost, c->stream));
+    if (a->mu) HIP_TRY(hipMemcpyAsync(a->mu, d_mu.p, (size_t)total * 4, hipMemcpyDeviceToHost, c->stream));
+    if (a->freq) HIP_TRY(hipMemcpyAsync(a->freq, d_freq.p, (size_t)total * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DSP_OK;
+}
+
 int dsp_synth_bursts_dev(dsp_ctx *c, uint64_t seed, int64_t b0, int64_t B, int n_sym, int sps,
                          const double *d_taps, int n_taps, double esn0_db, void *d_out_c64)
 {

@@ -57,7 +57,8 @@ hipError_t launch_sync(const SyncParams &P, bool c128, int variant, bool fll, si
 
 // tiling: burst-major [B][ld] <-> tiles
 hipError_t launch_tile_from_bursts(const void *src, int64_t ld, const int *lens, int len_all, int B,
-                                   void *dst, int rows, int elem_bytes, hipStream_t stream);
+                                   void *dst, int rows, int elem_bytes, hipStream_t stream,
+                                   const int64_t *starts = nullptr);
 hipError_t launch_bursts_from_tiles(const void *src, int rows, int B, void *dst, int64_t ld,
                                     int ncopy, int elem_bytes, hipStream_t stream);
 
@@ -70,6 +71,11 @@ struct FirParams {
     int64_t ld;               // samples between consecutive bursts (may be < N: overlapping views)
     const int *lens;          // [B] or NULL -> len_all
     int len_all, B;
+    // windows of ONE long stream (segment-parallel mode): burst b, sample n is stream sample
+    // starts[b] + n, present iff 0 <= starts[b] + n < n_total (so the filter sees the true
+    // neighbours across window edges and zeros only beyond the stream's own ends)
+    const int64_t *starts;    // [B] or NULL -> src + b * ld, zeros outside [0, len)
+    int64_t n_total;
     const double *h;          // device taps [M]
     int M, start;             // y[n] = sum_j h[j] x[n + start - j]
     const float *in_scale;    // device scalar applied to int16 samples in float32, or NULL
@@ -84,6 +90,8 @@ bool fir_plan(int in_kind, int M, int n_out, FirParams &P);
 hipError_t launch_fir_tile(const FirParams &P, int in_kind, hipStream_t s);
 hipError_t launch_fir_stats_finish(const double *stats, int nchunk, int B, double *std_out, double *inv_out,
                                    hipStream_t s);
+hipError_t launch_fir_stats_global(const double *stats, int64_t count, int B, double *std_out, double *inv_fill,
+                                   hipStream_t s);
 hipError_t launch_fir_direct(const FirParams &P, int in_kind, void *dst, int64_t dst_ld, int n_out, hipStream_t s);
 hipError_t launch_burst_std(const void *y, int c128, int64_t ld, const int *lens, int len_all, int B,
                             double *std_out, double *inv_out, hipStream_t s);
@@ -96,3 +104,25 @@ hipError_t launch_iq_i16(const void *raw, int64_t n, int normalize, unsigned *pe
 // synthetic burst generator (synth_kernels.hip)
 hipError_t launch_synth(uint64_t seed, int64_t b0, int B, int n_sym, int sps, const double *taps, int M,
                         float sigma, void *out, hipStream_t s);
+
+// ---------------------------------------------------------------------------
+// segment-parallel mode for one long capture (segment_kernels.hip)
+struct SegParams {
+    int S;                    // segments (= lanes of the recurrence kernel)
+    int sps, out_rows;
+    int64_t n_total, seg_len; // stream samples, samples per segment
+    const int64_t *starts;    // [S] stream sample of each window's first sample
+    const int *n_out;         // [S] symbols produced per window (rows of the tiled outputs)
+    const void *mu;           // tiled float32 mu history of the windows
+    const uint8_t *dec;       // tiled decisions
+    const void *freq;         // tiled float32 frequency (may be NULL)
+    int *j0, *j1;             // [S] kept rows [j0, j1) of each window
+    double *p_last;           // [S] stream position of row j1 - 1
+    int *rot;                 // [S] quadrant rotation of each window relative to its predecessor, then cumulative
+    int64_t *off;             // [S + 1] output offset of each window's first kept symbol
+};
+hipError_t launch_seg_windows(int S, int64_t n_total, int64_t seg_len, int64_t lead, int64_t tail,
+                              int64_t *starts, int *lens, hipStream_t s);
+hipError_t launch_seg_stitch(const SegParams &P, int overlap_vote, hipStream_t s);
+hipError_t launch_seg_gather(const SegParams &P, uint8_t *dec_out, float *mu_out, float *freq_out,
+                             int64_t capacity, hipStream_t s);

@@ -56,6 +56,17 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
         const int bb = w * 16 + q;
         const int b = tile * 64 + bb;
         const int len = b < P.B ? (P.lens ? P.lens[b] : P.len_all) : 0;
+        if (P.starts) {         // window of one long stream: true neighbours across the window edges
+            const int64_t st = b < P.B ? P.starts[b] : 0;
+            const IN *src = (const IN *)P.src;
+            for (int i = lane; i < W; i += 64) {
+                const int64_t g = st + x0 + i;
+                ST v = ST{0, 0};
+                if (b < P.B && g >= 0 && g < P.n_total) v = to_stage(src[g], isc);
+                xs[(size_t)bb * stride + i] = v;
+            }
+            continue;
+        }
         const IN *src = (const IN *)P.src + (int64_t)b * P.ld;
         for (int i = lane; i < W; i += 64) {
             const int n = x0 + i;
@@ -167,6 +178,47 @@ __global__ void fir_stats_finish(const double *__restrict__ stats, int nchunk, i
     const double sd = n > 0.0 ? sqrt(m2 / n) : __builtin_nan("");
     if (std_out) std_out[b] = sd;
     if (inv_out) inv_out[b] = 1.0 / sd;          // numpy: complex / real scalar = * (1/std)
+}
+
+// merge ALL partial statistics (every burst, every chunk) into one population std: the windows
+// of a segmented capture are normalised by the std of the whole filtered stream (worker.py:177
+// applied to one long signal).  One workgroup; inv_fill[0..B) all receive 1/std.
+__global__ __launch_bounds__(256) void fir_stats_global(const double *__restrict__ stats, int64_t count, int B,
+                                                        double *__restrict__ std_out, double *__restrict__ inv_fill)
+{
+    __shared__ double red[256 * 4];
+    double n = 0.0, mr = 0.0, mi = 0.0, m2 = 0.0;
+    for (int64_t c = threadIdx.x; c < count; c += 256) {
+        const double *s = stats + c * 4;
+        const double nb = s[0];
+        if (nb <= 0.0) continue;
+        const double nn = n + nb;
+        const double dr = s[1] - mr, di = s[2] - mi;
+        m2 += s[3] + (dr * dr + di * di) * (n * nb / nn);
+        mr += dr * (nb / nn);
+        mi += di * (nb / nn);
+        n = nn;
+    }
+    red[threadIdx.x * 4] = n; red[threadIdx.x * 4 + 1] = mr; red[threadIdx.x * 4 + 2] = mi; red[threadIdx.x * 4 + 3] = m2;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            double *a = red + threadIdx.x * 4;
+            const double *b = red + (threadIdx.x + st) * 4;
+            if (b[0] > 0.0) {
+                const double nn = a[0] + b[0];
+                const double dr = b[1] - a[1], di = b[2] - a[2];
+                a[3] += b[3] + (dr * dr + di * di) * (a[0] * b[0] / nn);
+                a[1] += dr * (b[0] / nn);
+                a[2] += di * (b[0] / nn);
+                a[0] = nn;
+            }
+        }
+        __syncthreads();
+    }
+    const double sd = red[0] > 0.0 ? sqrt(red[3] / red[0]) : __builtin_nan("");
+    if (threadIdx.x == 0 && std_out) *std_out = sd;
+    if (inv_fill) for (int b = threadIdx.x; b < B; b += 256) inv_fill[b] = 1.0 / sd;
 }
 
 // generic fallback for long filters: one thread per output sample, burst-major in and out
@@ -339,6 +391,13 @@ hipError_t launch_fir_stats_finish(const double *stats, int nchunk, int B, doubl
                                    hipStream_t s)
 {
     hipLaunchKernelGGL(fir_stats_finish, dim3((B + 255) / 256), dim3(256), 0, s, stats, nchunk, B, std_out, inv_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_fir_stats_global(const double *stats, int64_t count, int B, double *std_out, double *inv_fill,
+                                   hipStream_t s)
+{
+    hipLaunchKernelGGL(fir_stats_global, dim3(1), dim3(256), 0, s, stats, count, B, std_out, inv_fill);
     return hipGetLastError();
 }
 

@@ -1,0 +1,222 @@
+// segment_kernels.hip -- segment-parallel mode for ONE long capture (north-star (c)).
+//
+// The sequential loops of gardner2.py / fll_func.py cannot be parallelised inside one stream,
+// but they forget their start: after a warm-up the timing loop sits at the same mu wherever
+// it was started.  The capture is therefore cut into S segments of seg_len samples; segment s
+// becomes one lane ("burst") of the recurrence kernel that starts `lead` samples BEFORE its
+// seam (warm-up overlap) and runs `tail` samples past the next seam.  These kernels do the
+// bookkeeping around that launch:
+//
+//   seg_windows  window start / length of every segment
+//   seg_scan     per window: the stream position of every produced symbol (k + mu, with the
+//                k slips recovered from the +-sps jumps of the mu history); the last symbol in
+//                front of the window's closing seam ends the window's share
+//   seg_range    per window: its share starts half a symbol after the predecessor's last
+//                symbol, so shares tile the stream with no gap and no duplicate; the QPSK
+//                quadrant ambiguity of a freshly locked decision-directed loop is resolved by a
+//                vote over the symbols both windows decoded (the warm-up overlap)
+//   seg_offsets  exclusive scan of the share sizes, cumulative rotation
+//   seg_gather   rotated decisions (and mu / frequency) of all shares, concatenated
+//
+// There is no reference counterpart; the oracle restates the same
+// definition on the CPU (oracle/oracle.py sync_capture_segmented).
+#include "dsp_internal.h"
+
+namespace {
+
+// quadrant index (Re<0) + 2 (Im<0) after a turn by r * 90 degrees
+__device__ __forceinline__ unsigned rot_quadrant(unsigned q, int r)
+{
+    const unsigned turn[4] = {1u, 3u, 0u, 2u};       // +90 degrees: (re, im) -> (-im, re)
+    for (int i = 0; i < (r & 3); i++) q = turn[q & 3u];
+    return q & 3u;
+}
+
+__global__ void seg_windows_k(int S, int64_t n_total, int64_t seg_len, int64_t lead, int64_t tail,
+                              int64_t *__restrict__ starts, int *__restrict__ lens)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    int64_t st = (int64_t)s * seg_len - lead;
+    if (st < 0) st = 0;
+    int64_t en = (int64_t)(s + 1) * seg_len + tail;
+    if (en > n_total || s == S - 1) en = n_total;
+    starts[s] = st;
+    lens[s] = (int)(en - st);
+}
+
+// rows of a tiled float array of window s
+__device__ __forceinline__ float tile_f32(const void *base, int out_rows, int s, int row)
+{
+    return ((const float *)base)[((size_t)(s >> 6) * out_rows + row) * 64 + (s & 63)];
+}
+__device__ __forceinline__ unsigned tile_u8(const uint8_t *base, int out_rows, int s, int row)
+{
+    return base[((size_t)(s >> 6) * out_rows + row) * 64 + (s & 63)];
+}
+
+// Position of symbol row r >= 1 of a window: k_{r-1} + mu_{r-1} with k_{r-1} = sps * (r + slips)
+// (gardner2.py:61,65-70,95,98); row 0 is signal[0] of the window (gardner2.py:59).
+struct PosScan {
+    const void *mu; int out_rows, s, sps; double start;
+    int slips; float prev; int row;
+    __device__ void init(const SegParams &P, int seg)
+    {
+        mu = P.mu; out_rows = P.out_rows; s = seg; sps = P.sps; start = (double)P.starts[seg];
+        slips = 0; prev = 0.0f; row = 0;
+    }
+    // position of the next row (call once per row, rows ascending from 0)
+    __device__ double next()
+    {
+        const int r = row++;
+        if (r == 0) return start;
+        const float m = tile_f32(mu, out_rows, s, r - 1);
+        if (r > 1) {
+            const float d = m - prev;
+            if (d < -0.5f * (float)sps) slips += 1;          // mu >= sps wrapped: mu -= sps, k += sps
+            else if (d > 0.5f * (float)sps) slips -= 1;
+        }
+        prev = m;
+        return start + (double)sps * (double)(r + slips) + (double)m;
+    }
+};
+
+// one lane per window (lane = burst lane of the tiles: row reads are coalesced)
+__global__ __launch_bounds__(64) void seg_scan_k(SegParams P)
+{
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= P.S) return;
+    const int n = P.n_out[s];
+    const double seam_hi = (s == P.S - 1) ? 1.0e300 : (double)(s + 1) * (double)P.seg_len;
+    PosScan ps; ps.init(P, s);
+    int j1 = 0; double pl = -1.0e300;
+    for (int r = 0; r < n; r++) {
+        const double p = ps.next();
+        if (p < seam_hi) { j1 = r + 1; pl = p; }
+    }
+    P.j1[s] = j1;
+    P.p_last[s] = pl;
+}
+
+__global__ __launch_bounds__(64) void seg_range_k(SegParams P, int vote_len)
+{
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= P.S) return;
+    const int j1 = P.j1[s];
+    int j0 = 0, rot = 0;
+    if (s > 0) {
+        const double lo = P.p_last[s - 1] + 0.5 * (double)P.sps;
+        PosScan ps; ps.init(P, s);
+        j0 = j1;
+        for (int r = 0; r < j1; r++) {
+            if (ps.next() > lo) { j0 = r; break; }
+        }
+        // rows j0-1-m of this window and j1'-1-m of the predecessor are the same symbols
+        const int jp = P.j1[s - 1];
+        int V = vote_len;
+        if (V > j0) V = j0;
+        if (V > jp) V = jp;
+        int best = -1;
+        for (int r4 = 0; r4 < 4; r4++) {
+            int agree = 0;
+            for (int m = 0; m < V; m++) {
+                const unsigned a = rot_quadrant(tile_u8(P.dec, P.out_rows, s, j0 - 1 - m), r4);
+                const unsigned b = tile_u8(P.dec, P.out_rows, s - 1, jp - 1 - m);
+                agree += a == b;
+            }
+            if (agree > best) { best = agree; rot = r4; }
+        }
+    }
+    if (j0 > j1) j0 = j1;
+    P.j0[s] = j0;
+    P.rot[s] = rot;
+}
+
+// exclusive scan of the share sizes and running rotation (one workgroup; S <= a few 10^5)
+__global__ __launch_bounds__(1024) void seg_offsets_k(SegParams P)
+{
+    __shared__ long long cnt[1024];
+    __shared__ int rsum[1024];
+    const int t = threadIdx.x;
+    const int per = (P.S + 1023) / 1024;
+    const int lo = t * per, hi = (lo + per < P.S) ? lo + per : P.S;
+    long long c = 0; int r = 0;
+    for (int s = lo; s < hi; s++) { c += P.j1[s] - P.j0[s]; r += P.rot[s]; }
+    cnt[t] = c; rsum[t] = r;
+    __syncthreads();
+    if (t == 0) {
+        long long a = 0; int b = 0;
+        for (int i = 0; i < 1024; i++) { const long long c0 = cnt[i]; const int r0 = rsum[i]; cnt[i] = a; rsum[i] = b; a += c0; b += r0; }
+        P.off[P.S] = a;
+    }
+    __syncthreads();
+    long long a = cnt[t]; int b = rsum[t];
+    for (int s = lo; s < hi; s++) {
+        b += P.rot[s];                       // window s is turned by the sum of the relative turns up to s
+        P.off[s] = a;
+        a += P.j1[s] - P.j0[s];
+        P.rot[s] = b & 3;
+    }
+}
+
+// 64 windows x 64 rows per workgroup through LDS so that both sides are contiguous
+__global__ __launch_bounds__(256) void seg_gather_k(SegParams P, uint8_t *__restrict__ dec_out,
+                                                    float *__restrict__ mu_out, float *__restrict__ freq_out,
+                                                    int64_t capacity)
+{
+    __shared__ uint8_t td[64][68];
+    __shared__ float tm[64][65];
+    __shared__ float tf[64][65];
+    const int tile = blockIdx.y, r0 = blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = 0; i < 16; i++) {
+        const int rr = w * 16 + i, row = r0 + rr;
+        if (row < P.out_rows) {
+            const size_t at = ((size_t)tile * P.out_rows + row) * 64 + lane;
+            td[rr][lane] = P.dec[at];
+            // mu history row r-1 belongs to symbol row r
+            if (mu_out) tm[rr][lane] = row > 0 ? ((const float *)P.mu)[at - 64] : 0.0f;
+            if (freq_out) tf[rr][lane] = ((const float *)P.freq)[at];
+        }
+    }
+    __syncthreads();
+    for (int i = 0; i < 16; i++) {
+        const int bb = w * 16 + i, s = tile * 64 + bb;
+        if (s >= P.S) continue;
+        const int row = r0 + lane;
+        const int j0 = P.j0[s], j1 = P.j1[s];
+        if (row < j0 || row >= j1) continue;
+        const int64_t at = P.off[s] + (row - j0);
+        if (at >= capacity) continue;
+        dec_out[at] = (uint8_t)rot_quadrant(td[lane][bb], P.rot[s]);
+        if (mu_out) mu_out[at] = tm[lane][bb];
+        if (freq_out) freq_out[at] = tf[lane][bb];
+    }
+}
+
+}  // namespace
+
+hipError_t launch_seg_windows(int S, int64_t n_total, int64_t seg_len, int64_t lead, int64_t tail,
+                              int64_t *starts, int *lens, hipStream_t s)
+{
+    hipLaunchKernelGGL(seg_windows_k, dim3((S + 255) / 256), dim3(256), 0, s, S, n_total, seg_len, lead, tail,
+                       starts, lens);
+    return hipGetLastError();
+}
+
+hipError_t launch_seg_stitch(const SegParams &P, int overlap_vote, hipStream_t s)
+{
+    const int nb = (P.S + 63) / 64;
+    hipLaunchKernelGGL(seg_scan_k, dim3(nb), dim3(64), 0, s, P);
+    hipLaunchKernelGGL(seg_range_k, dim3(nb), dim3(64), 0, s, P, overlap_vote);
+    hipLaunchKernelGGL(seg_offsets_k, dim3(1), dim3(1024), 0, s, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_seg_gather(const SegParams &P, uint8_t *dec_out, float *mu_out, float *freq_out,
+                             int64_t capacity, hipStream_t s)
+{
+    dim3 grid((P.out_rows + 63) / 64, (P.S + 63) / 64);
+    hipLaunchKernelGGL(seg_gather_k, grid, dim3(256), 0, s, P, dec_out, mu_out, freq_out, capacity);
+    return hipGetLastError();
+}

@@ -10,11 +10,13 @@ namespace {
 
 template <typename E> struct Pad { enum { STRIDE = 64 + (sizeof(E) >= 8 ? 1 : (sizeof(E) == 4 ? 1 : 4)) }; };
 
-// src[b][n] -> dst[(b/64)*rows + n][b%64]; zero fill beyond lens[b] / B.
+// src[b][n] -> dst[(b/64)*rows + n][b%64]; zero fill beyond lens[b] / B.  With `starts`,
+// burst b is the window of one long stream that begins at sample starts[b].
 template <typename E>
 __global__ __launch_bounds__(256) void tile_from_bursts_k(const E *__restrict__ src, int64_t ld,
                                                          const int *__restrict__ lens, int len_all,
-                                                         int B, E *__restrict__ dst, int rows)
+                                                         int B, E *__restrict__ dst, int rows,
+                                                         const int64_t *__restrict__ starts)
 {
     __shared__ E t[64][Pad<E>::STRIDE];
     const int tile = blockIdx.y, n0 = blockIdx.x * 64;
@@ -26,7 +28,7 @@ __global__ __launch_bounds__(256) void tile_from_bursts_k(const E *__restrict__ 
         E v = E();
         if (b < B) {
             int len = lens ? lens[b] : len_all;
-            if (n < len) v = src[(int64_t)b * ld + n];
+            if (n < len) v = src[(starts ? starts[b] : (int64_t)b * ld) + n];
         }
         t[bb][lane] = v;
     }
@@ -65,18 +67,19 @@ __global__ __launch_bounds__(256) void bursts_from_tiles_k(const E *__restrict__
 }  // namespace
 
 hipError_t launch_tile_from_bursts(const void *src, int64_t ld, const int *lens, int len_all, int B,
-                                   void *dst, int rows, int elem_bytes, hipStream_t stream)
+                                   void *dst, int rows, int elem_bytes, hipStream_t stream,
+                                   const int64_t *starts)
 {
     if (B <= 0 || rows <= 0) return hipSuccess;
     dim3 grid((rows + 63) / 64, (B + 63) / 64), block(256);
     switch (elem_bytes) {
         case 8:
             hipLaunchKernelGGL(tile_from_bursts_k<float2>, grid, block, 0, stream, (const float2 *)src, ld,
-                               lens, len_all, B, (float2 *)dst, rows);
+                               lens, len_all, B, (float2 *)dst, rows, starts);
             break;
         case 16:
             hipLaunchKernelGGL(tile_from_bursts_k<double2>, grid, block, 0, stream, (const double2 *)src,
-                               ld, lens, len_all, B, (double2 *)dst, rows);
+                               ld, lens, len_all, B, (double2 *)dst, rows, starts);
             break;
         default:
             return hipErrorInvalidValue;

@@ -188,6 +188,44 @@ int64_t dsp_fir_workspace_bytes(int in_kind, int64_t B, int64_t N, int n_taps);
  * Returns DSP_E_ARG if the filter is too long for the LDS-tiled kernel (n_taps > ~80). */
 int dsp_fir_tiles_dev(dsp_ctx *ctx, const dsp_fir_args *args);
 
+/* ---- segment-parallel mode for ONE long capture (north-star (c)) ----------
+ * No counterpart in the reference, whose loops are strictly sequential (gardner2.py:63-98,
+ * fll_func.py:14-26).  The capture is cut into segments of seg_len samples; each segment is one
+ * lane of the batched recurrence kernel, started `warmup` symbols before its seam so that the
+ * loops have converged when the segment's own share begins, and the shares are stitched back:
+ * positions k+mu decide which symbols belong to which segment (no gap, no duplicate), the QPSK
+ * quadrant ambiguity between neighbouring segments is resolved over the symbols both decoded.
+ * The FLL's sample index (fll_func.py:16) restarts at every window start: with the reference's
+ * 2*pi*f*i phase the loop gain grows with i and the loop is unstable for i > 1/(pi*kp), so one
+ * run over a long capture is not a usable definition.
+ *   x        DSP_I16 interleaved int16 I,Q (peak-normalised like read_iq_int16 when normalize)
+ *            or DSP_C64 complex64 samples
+ *   h        matched-filter taps: np.convolve(x, h, 'same') / np.std over the WHOLE capture
+ *            (worker.py:173-178), or NULL = x is already filtered
+ *   outputs  one entry per symbol of the stitched stream (capacity entries available):
+ *            dec quadrant index, mu (float32, may be NULL), freq (float32, may be NULL);
+ *            *n_symbols receives the count; seg_info (may be NULL) [S][4] int32:
+ *            first kept row, end row, rotation applied, rows produced, per segment.
+ * dsp_sync_capture_segmented takes host pointers, ..._dev device pointers (n_symbols and
+ * seg_info stay host pointers; the call synchronises).                                        */
+typedef struct dsp_capture_args {
+    const void *x;
+    int32_t in_kind, normalize;
+    int64_t n_samples;
+    const double *h;
+    int32_t n_taps, sps;
+    double alpha, mu0, Bn, y;
+    int64_t seg_len, warmup;
+    uint8_t *dec;
+    float *mu, *freq;
+    int64_t capacity;
+    int64_t *n_symbols;
+    int32_t *seg_info;
+} dsp_capture_args;
+int dsp_sync_capture_segmented(dsp_ctx *ctx, const dsp_capture_args *args);
+int dsp_sync_capture_segmented_dev(dsp_ctx *ctx, const dsp_capture_args *args);
+int64_t dsp_capture_segments(int64_t n_samples, int64_t seg_len);   /* S = ceil(n / seg_len) */
+
 /* Synthetic QPSK bursts generated on the device (benchmarks / full-size tests; recipe of
  * SURVEY.md 8d after worker.py:339-427, counter-based RNG): bursts b0 .. b0+B-1 of n_sym*sps
  * complex64 samples, burst-major, at the TX output + channel (before the RX matched filter).

@@ -220,3 +220,78 @@ def sync_chain_c64(x, sps=4, alpha=0.007, mu0=0.0, Bn=0.03, y=1.0, scale=1.0, wa
         return dict(n=n, rec=rec[:n], err=err[:n - 1], mu=mu[:n - 1], sig=sig[:n],
                     freq=freq[:n], ef=ef[:n], dec=dec[:n])
     return dict(n=n, dec=dec[:n])
+
+
+# ---------------------------------------------------------------------------
+# Segment-parallel mode (no reference counterpart: the definition of include/dsp_hip.h
+# dsp_sync_capture_segmented restated with the sequential oracle loops above and numpy).
+_TURN = np.array([1, 3, 0, 2], np.uint8)        # quadrant index after +90 degrees
+
+
+def _positions(start, mu, n, sps):
+    """Stream position of symbol rows 0..n-1 of a window: row 0 is the window's first sample
+    (gardner2.py:59), row r >= 1 is k + mu with k = sps*(r + slips) (gardner2.py:61,65-70,95,98);
+    a slip shows as a jump of -+sps in the float32 mu history."""
+    p = np.empty(n)
+    p[0] = start
+    if n > 1:
+        m = mu[:n - 1].astype(np.float32)
+        d = np.diff(m)
+        step = np.zeros(n - 1, np.int64)
+        step[1:][d < np.float32(-0.5 * sps)] = 1
+        step[1:][d > np.float32(0.5 * sps)] = -1
+        slips = np.cumsum(step)
+        r = np.arange(1, n)
+        p[1:] = start + sps * (r + slips).astype(np.float64) + m.astype(np.float64)
+    return p
+
+
+def sync_capture_segmented(x, sps=4, alpha=0.007, mu0=0.0, Bn=0.003, y=1.0, seg_len=65536, warmup=2048,
+                           vote=None):
+    """x: the whole capture, complex64, already matched-filtered and normalised."""
+    x = np.ascontiguousarray(x, dtype=np.complex64)
+    n = x.size
+    S = (n + seg_len - 1) // seg_len
+    lead, tail = warmup * sps, 4 * sps + 8
+    vote = min(256, warmup // 2) if vote is None else vote
+    wins = []
+    for s in range(S):
+        st = max(0, s * seg_len - lead)
+        en = n if s == S - 1 else min(n, (s + 1) * seg_len + tail)
+        o = sync_chain_c64(x[st:en], sps=sps, alpha=alpha, mu0=mu0, Bn=Bn, y=y)
+        pos = _positions(float(st), o["mu"], o["n"], sps)
+        wins.append((o, pos))
+    dec, mu, freq, info = [], [], [], np.zeros((S, 4), np.int32)
+    p_last, j1_prev, rot_cum = None, None, 0
+    for s, (o, pos) in enumerate(wins):
+        seam_hi = np.inf if s == S - 1 else float((s + 1) * seg_len)
+        keep = np.nonzero(pos < seam_hi)[0]
+        j1 = int(keep[-1]) + 1 if keep.size else 0
+        pl = pos[j1 - 1] if j1 else -np.inf
+        j0, rot = 0, 0
+        if s > 0:
+            later = np.nonzero(pos[:j1] > p_last + 0.5 * sps)[0]
+            j0 = int(later[0]) if later.size else j1
+            V = min(vote, j0, j1_prev)
+            prev = wins[s - 1][0]["dec"]
+            best = -1
+            for r4 in range(4):
+                a = o["dec"][j0 - V:j0].copy()
+                for _ in range(r4):
+                    a = _TURN[a]
+                agree = int(np.sum(a == prev[j1_prev - V:j1_prev]))
+                if agree > best:
+                    best, rot = agree, r4
+        j0 = min(j0, j1)
+        rot_cum = (rot_cum + rot) & 3
+        d = o["dec"][j0:j1].copy()
+        for _ in range(rot_cum):
+            d = _TURN[d]
+        dec.append(d)
+        m_sym = np.concatenate(([0.0], o["mu"]))[:o["n"]]      # mu history row r-1 belongs to symbol r
+        mu.append(m_sym[j0:j1].astype(np.float32))
+        freq.append(o["freq"][j0:j1].astype(np.float32))
+        info[s] = (j0, j1, rot_cum, o["n"])
+        p_last, j1_prev = pl, j1
+    dec = np.concatenate(dec) if dec else np.zeros(0, np.uint8)
+    return dict(n=dec.size, dec=dec, mu=np.concatenate(mu), freq=np.concatenate(freq), seg_info=info)
