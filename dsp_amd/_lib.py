@@ -37,7 +37,7 @@ class SyncArgs(C.Structure):
         ("i0", C.c_void_p), ("fll_state_in", C.c_void_p), ("fll_state_out", C.c_void_p),
         ("rec", C.c_void_p), ("err", C.c_void_p), ("mu", C.c_void_p), ("sig", C.c_void_p),
         ("freq", C.c_void_p), ("ef", C.c_void_p), ("dec", C.c_void_p),
-        ("out_rows", C.c_int64), ("n_out", C.c_void_p), ("status", C.c_void_p),
+        ("out_rows", C.c_int64), ("n_out", C.c_void_p), ("status", C.c_void_p), ("pos", C.c_void_p),
     ]
 
 
@@ -133,6 +133,7 @@ def _declare(L):
     L.dsp_fir_workspace_bytes.restype = i64
     L.dsp_fir_tiles_dev.argtypes = [vp, C.POINTER(FirArgs)]
     L.dsp_synth_bursts_dev.argtypes = [vp, C.c_uint64, i64, i64, ci, ci, vp, ci, dbl, vp]
+    L.dsp_synth_stream_dev.argtypes = [vp, C.c_uint64, i64, ci, vp, ci, dbl, dbl, dbl, dbl, ci, dbl, vp]
     L.dsp_sync_capture_segmented.argtypes = [vp, C.POINTER(CaptureArgs)]
     L.dsp_sync_capture_segmented_dev.argtypes = [vp, C.POINTER(CaptureArgs)]
     L.dsp_capture_segments.argtypes = [i64, i64]
@@ -143,7 +144,7 @@ def _declare(L):
                  "dsp_gardner", "dsp_fll", "dsp_sync_chain", "dsp_tile_bursts_dev",
                  "dsp_untile_dev", "dsp_sync_tiles_dev", "dsp_load_iq_i16", "dsp_load_iq_f32",
                  "dsp_fir_same_std", "dsp_rx_chain", "dsp_fir_tiles_dev", "dsp_synth_bursts_dev",
-                 "dsp_sync_capture_segmented", "dsp_sync_capture_segmented_dev"):
+                 "dsp_sync_capture_segmented", "dsp_sync_capture_segmented_dev", "dsp_synth_stream_dev"):
         getattr(L, name).restype = ci
 
 

@@ -315,6 +315,7 @@ int dsp_sync_tiles_dev(dsp_ctx *c, const dsp_sync_args *a)
     P.rec = a->variant == 2 ? nullptr : a->rec;
     P.terr = a->variant == 2 ? nullptr : a->err;
     P.mu = a->variant == 2 ? nullptr : a->mu;
+    P.pos = a->variant == 2 ? nullptr : a->pos;
     P.sig = fll ? a->sig : nullptr; P.freq = fll ? a->freq : nullptr; P.ef = fll ? a->ef : nullptr;
     P.dec = fll ? a->dec : nullptr;
     P.out_rows = (int)a->out_rows; P.n_out = a->n_out; P.status = a->status;
@@ -330,7 +331,7 @@ int dsp_sync_tiles_dev(dsp_ctx *c, const dsp_sync_args *a)
     const int ntiles = (P.B + 63) / 64;
     const bool can_split = fll && a->variant != 2 && P.half_len == 0;
     const bool split = can_split && c->split != 0;
-    const int n_store_t = count_nonnull({P.rec, P.terr, P.mu});
+    const int n_store_t = count_nonnull({P.rec, P.terr, P.mu, P.pos});
     const int n_store_f = count_nonnull({P.sig, P.freq, P.ef, P.dec});
     const int n_store = split ? n_store_t : n_store_t + n_store_f;
     int per_cu = (ntiles + 255) / 256;
@@ -788,10 +789,11 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
     hipStream_t st = c->stream;
     HIP_TRY(hipSetDevice(c->device));
 
-    DevBuf d_starts, d_lens, d_tiles, d_mu, d_dec, d_freq, d_nout, d_status, d_j0, d_j1, d_rot, d_pl, d_off;
+    DevBuf d_starts, d_lens, d_tiles, d_mu, d_pos, d_dec, d_freq, d_nout, d_status, d_j0, d_j1, d_rot, d_pl, d_off;
     HIP_TRY(d_starts.alloc((size_t)S * 8)); HIP_TRY(d_lens.alloc((size_t)S * 4));
     HIP_TRY(d_tiles.alloc((size_t)ntiles * rows * 64 * 8));
-    HIP_TRY(d_mu.alloc((size_t)ntiles * out_rows * 64 * 4));
+    if (a->mu) HIP_TRY(d_mu.alloc((size_t)ntiles * out_rows * 64 * 4));
+    HIP_TRY(d_pos.alloc((size_t)ntiles * out_rows * 64 * 4));
     HIP_TRY(d_dec.alloc((size_t)ntiles * out_rows * 64));
     if (a->freq) HIP_TRY(d_freq.alloc((size_t)ntiles * out_rows * 64 * 4));
     HIP_TRY(d_nout.alloc((size_t)S * 4)); HIP_TRY(d_status.alloc((size_t)S * 4));
@@ -800,7 +802,7 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
     HIP_TRY(hipMemsetAsync(d_tiles.p, 0, (size_t)ntiles * rows * 64 * 8, st));
 
     // ---- windows -> tiles (optionally through the matched filter) ------------------------
-    DevBuf d_peak, d_c64, d_ws, d_inv, d_starts0, d_lens0;
+    DevBuf d_peak, d_c64, d_ws, d_inv, d_starts0, d_lens0, d_part;
     const float *in_scale = nullptr;
     if (a->in_kind == DSP_I16) {
         HIP_TRY(d_peak.alloc(16));
@@ -824,7 +826,9 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
         P.len_all = (int)seg; P.B = S; P.h = a->h; P.M = a->n_taps; P.start = (a->n_taps - 1) / 2;
         P.in_scale = in_scale; P.dst = nullptr; P.rows = (int)rows; P.stats = d_ws.as<double>();
         HIP_TRY(launch_fir_tile(P, a->in_kind, st));
-        HIP_TRY(launch_fir_stats_global(P.stats, (int64_t)S * P.nchunk, S, nullptr, d_inv.as<double>(), st));
+        HIP_TRY(d_part.alloc((size_t)1024 * 32));
+        HIP_TRY(launch_fir_stats_global(P.stats, (int64_t)S * P.nchunk, S, nullptr, d_inv.as<double>(),
+                                        d_part.as<double>(), 1024, st));
         // pass 2: the overlapping windows, scaled by 1/std, one rounding into complex64
         FirParams Q;
         memset(&Q, 0, sizeof(Q));
@@ -844,7 +848,7 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
     memset(&sa, 0, sizeof(sa));
     sa.x = d_tiles.p; sa.dtype = DSP_C64; sa.variant = DSP_GARDNER2; sa.B = S; sa.N = Nw; sa.in_rows = rows;
     sa.lens = d_lens.as<int32_t>(); sa.sps = sps; sa.alpha = a->alpha; sa.mu0 = a->mu0; sa.do_fll = 1;
-    sa.Bn = a->Bn; sa.y = a->y; sa.mu = d_mu.p; sa.dec = d_dec.as<uint8_t>(); sa.freq = a->freq ? d_freq.p : nullptr;
+    sa.Bn = a->Bn; sa.y = a->y; sa.mu = a->mu ? d_mu.p : nullptr; sa.pos = d_pos.p; sa.dec = d_dec.as<uint8_t>(); sa.freq = a->freq ? d_freq.p : nullptr;
     sa.out_rows = out_rows; sa.n_out = d_nout.as<int32_t>(); sa.status = d_status.as<int32_t>();
     {
         int rc = dsp_sync_tiles_dev(c, &sa);
@@ -855,7 +859,7 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
     SegParams G;
     memset(&G, 0, sizeof(G));
     G.S = S; G.sps = sps; G.out_rows = (int)out_rows; G.n_total = n; G.seg_len = seg;
-    G.starts = d_starts.as<int64_t>(); G.n_out = d_nout.as<int>(); G.mu = d_mu.p; G.dec = d_dec.as<uint8_t>();
+    G.starts = d_starts.as<int64_t>(); G.n_out = d_nout.as<int>(); G.mu = a->mu ? d_mu.p : nullptr; G.pos = d_pos.p; G.dec = d_dec.as<uint8_t>();
     G.freq = a->freq ? d_freq.p : nullptr;
     G.j0 = d_j0.as<int>(); G.j1 = d_j1.as<int>(); G.p_last = d_pl.as<double>(); G.rot = d_rot.as<int>();
     G.off = d_off.as<int64_t>();
@@ -926,6 +930,20 @@ int dsp_synth_bursts_dev(dsp_ctx *c, uint64_t seed, int64_t b0, int64_t B, int n
     const float sigma = (float)sqrt(pow(10.0, -esn0_db / 10.0));
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(launch_synth(seed, b0, (int)B, n_sym, sps, d_taps, n_taps, sigma, d_out_c64, c->stream));
+    return DSP_OK;
+}
+
+int dsp_synth_stream_dev(dsp_ctx *c, uint64_t seed, int64_t n_samples, int sps, const double *d_taps,
+                         int n_taps, double esn0_db, double cfo, double tau0, double drift, int out_kind,
+                         double amplitude, void *d_out)
+{
+    if (!c || !d_taps || !d_out) return fail(DSP_E_ARG, "synth: NULL argument");
+    if (n_samples < 1 || sps < 1 || n_taps < 1 || n_taps > 512) return fail(DSP_E_ARG, "synth: bad n / sps / n_taps");
+    if (out_kind != DSP_I16 && out_kind != DSP_C64) return fail(DSP_E_ARG, "synth: out_kind must be DSP_I16 or DSP_C64");
+    const float sigma = (float)sqrt(pow(10.0, -esn0_db / 10.0));
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_synth_stream(seed, n_samples, sps, d_taps, n_taps, sigma, cfo, tau0, drift,
+                                out_kind == DSP_I16, (float)amplitude, d_out, c->stream));
     return DSP_OK;
 }
 

@@ -35,6 +35,7 @@ struct SyncParams {
     // outputs, tiled [ntiles][out_rows][64]; any may be NULL
     void *rec, *terr, *mu, *sig, *freq, *ef;
     uint8_t *dec;
+    void *pos;                // sample position k + mu of every recovered symbol (row r = symbol r + 1), or NULL
     int out_rows;
     int *n_out;               // [B] number of symbols produced
     int *status;              // [B] bit0: output capacity reached before the loop ended
@@ -91,7 +92,7 @@ hipError_t launch_fir_tile(const FirParams &P, int in_kind, hipStream_t s);
 hipError_t launch_fir_stats_finish(const double *stats, int nchunk, int B, double *std_out, double *inv_out,
                                    hipStream_t s);
 hipError_t launch_fir_stats_global(const double *stats, int64_t count, int B, double *std_out, double *inv_fill,
-                                   hipStream_t s);
+                                   double *partial, int n_partial, hipStream_t s);
 hipError_t launch_fir_direct(const FirParams &P, int in_kind, void *dst, int64_t dst_ld, int n_out, hipStream_t s);
 hipError_t launch_burst_std(const void *y, int c128, int64_t ld, const int *lens, int len_all, int B,
                             double *std_out, double *inv_out, hipStream_t s);
@@ -105,6 +106,9 @@ hipError_t launch_iq_i16(const void *raw, int64_t n, int normalize, unsigned *pe
 hipError_t launch_synth(uint64_t seed, int64_t b0, int B, int n_sym, int sps, const double *taps, int M,
                         float sigma, void *out, hipStream_t s);
 
+hipError_t launch_synth_stream(uint64_t seed, int64_t n_total, int sps, const double *taps, int M, float sigma,
+                               double cfo, double tau0, double drift, int i16, float amp, void *out, hipStream_t s);
+
 // ---------------------------------------------------------------------------
 // segment-parallel mode for one long capture (segment_kernels.hip)
 struct SegParams {
@@ -114,6 +118,7 @@ struct SegParams {
     const int64_t *starts;    // [S] stream sample of each window's first sample
     const int *n_out;         // [S] symbols produced per window (rows of the tiled outputs)
     const void *mu;           // tiled float32 mu history of the windows
+    const void *pos;          // tiled float32 window-local position of every symbol (row r = symbol r + 1)
     const uint8_t *dec;       // tiled decisions
     const void *freq;         // tiled float32 frequency (may be NULL)
     int *j0, *j1;             // [S] kept rows [j0, j1) of each window

@@ -183,12 +183,17 @@ __global__ void fir_stats_finish(const double *__restrict__ stats, int nchunk, i
 // merge ALL partial statistics (every burst, every chunk) into one population std: the windows
 // of a segmented capture are normalised by the std of the whole filtered stream (worker.py:177
 // applied to one long signal).  One workgroup; inv_fill[0..B) all receive 1/std.
+// With `partial` the workgroups each merge a slice and write one (n, mean, M2) record; the last
+// step (partial == NULL, one workgroup) merges those records and produces the result.
 __global__ __launch_bounds__(256) void fir_stats_global(const double *__restrict__ stats, int64_t count, int B,
-                                                        double *__restrict__ std_out, double *__restrict__ inv_fill)
+                                                        double *__restrict__ std_out, double *__restrict__ inv_fill,
+                                                        double *__restrict__ partial)
 {
     __shared__ double red[256 * 4];
     double n = 0.0, mr = 0.0, mi = 0.0, m2 = 0.0;
-    for (int64_t c = threadIdx.x; c < count; c += 256) {
+    const int64_t per = (count + gridDim.x - 1) / gridDim.x;
+    const int64_t c_lo = blockIdx.x * per, c_hi = c_lo + per < count ? c_lo + per : count;
+    for (int64_t c = c_lo + threadIdx.x; c < c_hi; c += 256) {
         const double *s = stats + c * 4;
         const double nb = s[0];
         if (nb <= 0.0) continue;
@@ -215,6 +220,10 @@ __global__ __launch_bounds__(256) void fir_stats_global(const double *__restrict
             }
         }
         __syncthreads();
+    }
+    if (partial) {
+        if (threadIdx.x < 4) partial[blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x];
+        return;
     }
     const double sd = red[0] > 0.0 ? sqrt(red[3] / red[0]) : __builtin_nan("");
     if (threadIdx.x == 0 && std_out) *std_out = sd;
@@ -395,9 +404,15 @@ hipError_t launch_fir_stats_finish(const double *stats, int nchunk, int B, doubl
 }
 
 hipError_t launch_fir_stats_global(const double *stats, int64_t count, int B, double *std_out, double *inv_fill,
-                                   hipStream_t s)
+                                   double *partial, int n_partial, hipStream_t s)
 {
-    hipLaunchKernelGGL(fir_stats_global, dim3(1), dim3(256), 0, s, stats, count, B, std_out, inv_fill);
+    if (partial && n_partial > 1 && count > 4096) {
+        hipLaunchKernelGGL(fir_stats_global, dim3(n_partial), dim3(256), 0, s, stats, count, B, nullptr, nullptr, partial);
+        hipLaunchKernelGGL(fir_stats_global, dim3(1), dim3(256), 0, s, partial, (int64_t)n_partial, B, std_out, inv_fill,
+                           nullptr);
+    } else {
+        hipLaunchKernelGGL(fir_stats_global, dim3(1), dim3(256), 0, s, stats, count, B, std_out, inv_fill, nullptr);
+    }
     return hipGetLastError();
 }
 

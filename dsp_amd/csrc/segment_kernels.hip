@@ -8,9 +8,9 @@
 // bookkeeping around that launch:
 //
 //   seg_windows  window start / length of every segment
-//   seg_scan     per window: the stream position of every produced symbol (k + mu, with the
-//                k slips recovered from the +-sps jumps of the mu history); the last symbol in
-//                front of the window's closing seam ends the window's share
+//   seg_scan     per window: the recurrence kernel wrote the sample position k + mu of every
+//                produced symbol; the last symbol in front of the window's closing seam ends
+//                the window's share (binary search, positions are increasing)
 //   seg_range    per window: its share starts half a symbol after the predecessor's last
 //                symbol, so shares tile the stream with no gap and no duplicate; the QPSK
 //                quadrant ambiguity of a freshly locked decision-directed loop is resolved by a
@@ -55,47 +55,37 @@ __device__ __forceinline__ unsigned tile_u8(const uint8_t *base, int out_rows, i
     return base[((size_t)(s >> 6) * out_rows + row) * 64 + (s & 63)];
 }
 
-// Position of symbol row r >= 1 of a window: k_{r-1} + mu_{r-1} with k_{r-1} = sps * (r + slips)
-// (gardner2.py:61,65-70,95,98); row 0 is signal[0] of the window (gardner2.py:59).
-struct PosScan {
-    const void *mu; int out_rows, s, sps; double start;
-    int slips; float prev; int row;
-    __device__ void init(const SegParams &P, int seg)
-    {
-        mu = P.mu; out_rows = P.out_rows; s = seg; sps = P.sps; start = (double)P.starts[seg];
-        slips = 0; prev = 0.0f; row = 0;
+// Stream position of symbol row r of window s: row 0 is the window's first sample
+// (gardner2.py:59), row r >= 1 is k + mu of the iteration that produced it (gardner2.py:95), which
+// the recurrence kernel wrote to row r - 1 of `pos`.  Positions grow by sps + (mu change) per
+// row, so they are strictly increasing and a binary search finds the seams.
+__device__ __forceinline__ double row_position(const SegParams &P, int s, int r)
+{
+    const double st = (double)P.starts[s];
+    return r == 0 ? st : st + (double)tile_f32(P.pos, P.out_rows, s, r - 1);
+}
+// number of rows r in [0, n) with position < x (strict = true) or <= x
+__device__ __forceinline__ int rows_below(const SegParams &P, int s, int n, double x, bool strict)
+{
+    int lo = 0, hi = n;                      // invariant: rows < lo are below, rows >= hi are not
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const double p = row_position(P, s, mid);
+        if (strict ? p < x : p <= x) lo = mid + 1; else hi = mid;
     }
-    // position of the next row (call once per row, rows ascending from 0)
-    __device__ double next()
-    {
-        const int r = row++;
-        if (r == 0) return start;
-        const float m = tile_f32(mu, out_rows, s, r - 1);
-        if (r > 1) {
-            const float d = m - prev;
-            if (d < -0.5f * (float)sps) slips += 1;          // mu >= sps wrapped: mu -= sps, k += sps
-            else if (d > 0.5f * (float)sps) slips -= 1;
-        }
-        prev = m;
-        return start + (double)sps * (double)(r + slips) + (double)m;
-    }
-};
+    return lo;
+}
 
-// one lane per window (lane = burst lane of the tiles: row reads are coalesced)
+// one lane per window: the last symbol in front of the window's closing seam ends its share
 __global__ __launch_bounds__(64) void seg_scan_k(SegParams P)
 {
     const int s = blockIdx.x * 64 + threadIdx.x;
     if (s >= P.S) return;
     const int n = P.n_out[s];
-    const double seam_hi = (s == P.S - 1) ? 1.0e300 : (double)(s + 1) * (double)P.seg_len;
-    PosScan ps; ps.init(P, s);
-    int j1 = 0; double pl = -1.0e300;
-    for (int r = 0; r < n; r++) {
-        const double p = ps.next();
-        if (p < seam_hi) { j1 = r + 1; pl = p; }
-    }
+    int j1 = n;
+    if (s != P.S - 1) j1 = rows_below(P, s, n, (double)(s + 1) * (double)P.seg_len, true);
     P.j1[s] = j1;
-    P.p_last[s] = pl;
+    P.p_last[s] = j1 > 0 ? row_position(P, s, j1 - 1) : -1.0e300;
 }
 
 __global__ __launch_bounds__(64) void seg_range_k(SegParams P, int vote_len)
@@ -105,12 +95,8 @@ __global__ __launch_bounds__(64) void seg_range_k(SegParams P, int vote_len)
     const int j1 = P.j1[s];
     int j0 = 0, rot = 0;
     if (s > 0) {
-        const double lo = P.p_last[s - 1] + 0.5 * (double)P.sps;
-        PosScan ps; ps.init(P, s);
-        j0 = j1;
-        for (int r = 0; r < j1; r++) {
-            if (ps.next() > lo) { j0 = r; break; }
-        }
+        // the share starts with the first symbol more than half a symbol after the predecessor's last
+        j0 = rows_below(P, s, j1, P.p_last[s - 1] + 0.5 * (double)P.sps, false);
         // rows j0-1-m of this window and j1'-1-m of the predecessor are the same symbols
         const int jp = P.j1[s - 1];
         int V = vote_len;

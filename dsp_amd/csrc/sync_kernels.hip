@@ -357,6 +357,14 @@ __device__ __forceinline__ bool g2_steady(const Tile<IN> &tl, dspm::GState &gs, 
     return true;
 }
 
+// sample position of the symbol an iteration just produced: k + mu with the updated mu
+// (gardner2.py:95) / idx_k (hw1/gardner.py:47); the k in gs has already advanced
+template <int VARIANT>
+__device__ __forceinline__ double symbol_position(const dspm::GState &gs, const dspm::GOut &go, int sps)
+{
+    return VARIANT == DSP_VARIANT_TED ? (double)((gs.k - 1) * sps) + go.mu : (double)(gs.k - sps) + go.mu;
+}
+
 // FLL step for every lane, committed by select (no divergent control flow)
 struct FllLane { double sr, si, ef, freq; unsigned quad; };
 __device__ __forceinline__ FllLane fll_iter(const dspm::MathK &MK, bool pending, cd x, double idx,
@@ -441,7 +449,7 @@ __global__ __launch_bounds__(64) void sync_kernel(SyncParams P)
     dspm::MathK MK;
     if (FLL) MK = load_math_consts();
 
-    OC *o_rec = (OC *)P.rec; OS *o_terr = (OS *)P.terr; OS *o_mu = (OS *)P.mu;
+    OC *o_rec = (OC *)P.rec; OS *o_terr = (OS *)P.terr; OS *o_mu = (OS *)P.mu; OS *o_pos = (OS *)P.pos;
     OC *o_sig = (OC *)P.sig; OS *o_freq = (OS *)P.freq; OS *o_ef = (OS *)P.ef;
     uint8_t *o_dec = P.dec;
 
@@ -499,6 +507,7 @@ __global__ __launch_bounds__(64) void sync_kernel(SyncParams P)
                 if (o_rec) st_cplx(o_rec + obase + (size_t)rrow * 64, go.rec.re, go.rec.im, go.produced);
                 if (o_terr) st_val(o_terr + g_off, go.err, go.produced);
                 if (o_mu) st_val(o_mu + g_off, go.mu, go.produced);
+                if (o_pos) st_val(o_pos + g_off, symbol_position<VARIANT>(gs, go, sps), go.produced);
             }
             pending = go.produced;
             rec_prev = go.rec;
@@ -596,7 +605,7 @@ __global__ __launch_bounds__(128) void sync_split_kernel(SyncParams P)
         TimingConst tc;
         dspm::GState gs;
         timing_init(tc, gs, P, VARIANT, len, lane_ok);
-        OC *o_rec = (OC *)P.rec; OS *o_terr = (OS *)P.terr; OS *o_mu = (OS *)P.mu;
+        OC *o_rec = (OC *)P.rec; OS *o_terr = (OS *)P.terr; OS *o_mu = (OS *)P.mu; OS *o_pos = (OS *)P.pos;
         int n_rec = 0;
         if (VARIANT == DSP_VARIANT_GARDNER2) {
             cd r0; r0.re = 0.0; r0.im = 0.0;
@@ -608,7 +617,7 @@ __global__ __launch_bounds__(128) void sync_split_kernel(SyncParams P)
         int min_len = len;
         for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(min_len, d); min_len = o < min_len ? o : min_len; }
         min_len = __builtin_amdgcn_readfirstlane(min_len);
-        const bool steady_ok = VARIANT == DSP_VARIANT_GARDNER2 && ring && o_rec && o_terr && o_mu;
+        const bool steady_ok = VARIANT == DSP_VARIANT_GARDNER2 && ring && o_rec && o_terr && o_mu && !o_pos;
         bool all_active = __all(gs.active);
         const unsigned char *rec_t = (const unsigned char *)(o_rec + (size_t)tile * out_rows * 64);
         const unsigned char *err_t = (const unsigned char *)(o_terr + (size_t)tile * out_rows * 64);
@@ -657,6 +666,7 @@ __global__ __launch_bounds__(128) void sync_split_kernel(SyncParams P)
                     if (o_rec) st_cplx(o_rec + obase + (size_t)rrow * 64, go.rec.re, go.rec.im, go.produced);
                     if (o_terr) st_val(o_terr + g_off, go.err, go.produced);
                     if (o_mu) st_val(o_mu + g_off, go.mu, go.produced);
+                    if (o_pos) st_val(o_pos + g_off, symbol_position<VARIANT>(gs, go, sps), go.produced);
                     DSP_TR(trp, 6);
                     d2v qv = {go.rec.re, go.rec.im};
                     q_data[(buf * TQ + tq) * 64 + lane] = qv;

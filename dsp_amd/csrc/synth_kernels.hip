@@ -78,7 +78,73 @@ __global__ __launch_bounds__(256) void synth_kernel(uint64_t seed, int64_t b0, i
     out[(size_t)b * N + n] = f2v{xr * cs - xi * sn + r * nc, xr * sn + xi * cs + r * ns};
 }
 
+// One continuous QPSK stream (config 5): the burst recipe without ends, a timing offset that
+// drifts slowly (tau0 + drift * n samples) and one carrier offset; int16 I,Q (amplitude `amp`
+// counts per unit) or complex64.  Symbol i of the stream is rnd(splitmix64(seed), 1, i) & 3.
+template <bool I16>
+__global__ __launch_bounds__(256) void synth_stream_kernel(uint64_t seed, int64_t n_total, int sps,
+                                                           const double *__restrict__ taps, int M, float sigma,
+                                                           double cfo, double tau0, double drift, float amp,
+                                                           void *__restrict__ out)
+{
+    __shared__ float h[512];
+    for (int i = threadIdx.x; i < M; i += 256) h[i] = (float)taps[i];
+    __syncthreads();
+    const uint64_t key = splitmix64(seed);
+    const int start = (M - 1) / 2;
+    for (int64_t n = blockIdx.x * (int64_t)256 + threadIdx.x; n < n_total; n += (int64_t)gridDim.x * 256) {
+        double pos = (double)n + tau0 + drift * (double)n;
+        pos = pos < 0.0 ? 0.0 : pos;
+        const int64_t k = (int64_t)pos;
+        const float frac = (float)(pos - (double)k);
+        float txr[2] = {0.f, 0.f}, txi[2] = {0.f, 0.f};
+        for (int t = 0; t < 2; t++) {
+            const int64_t m = k + t + start;
+            int j = (int)(m % sps);
+            for (; j < M; j += sps) {
+                if (m - j < 0) break;
+                const uint64_t i = (uint64_t)((m - j) / sps);
+                const unsigned q = (unsigned)(rnd(key, 1, i) & 3);
+                txr[t] += h[j] * ((q & 1) ? -0.70710678f : 0.70710678f);
+                txi[t] += h[j] * ((q & 2) ? -0.70710678f : 0.70710678f);
+            }
+        }
+        const float xr = txr[0] * (1.f - frac) + txr[1] * frac;
+        const float xi = txi[0] * (1.f - frac) + txi[1] * frac;
+        double cyc = cfo * (double)n;                     // carrier phase in cycles, reduced exactly
+        cyc -= floor(cyc);
+        float sn, cs;
+        __sincosf((float)(6.283185307179586 * cyc), &sn, &cs);
+        const double u1 = u01(rnd(key, 3, (uint64_t)n)), u2 = u01(rnd(key, 4, (uint64_t)n));
+        const float r = sqrtf(-2.f * __logf((float)u1)) * sigma * 0.70710678f;
+        float ns, nc;
+        __sincosf(6.2831853f * (float)u2, &ns, &nc);
+        const float yr = xr * cs - xi * sn + r * nc, yi = xr * sn + xi * cs + r * ns;
+        if (I16) {
+            float a = rintf(yr * amp), b = rintf(yi * amp);
+            a = fminf(fmaxf(a, -32767.f), 32767.f);
+            b = fminf(fmaxf(b, -32767.f), 32767.f);
+            ((short2 *)out)[n] = make_short2((short)a, (short)b);
+        } else {
+            ((f2v *)out)[n] = f2v{yr, yi};
+        }
+    }
+}
+
 }  // namespace
+
+hipError_t launch_synth_stream(uint64_t seed, int64_t n_total, int sps, const double *taps, int M, float sigma,
+                               double cfo, double tau0, double drift, int i16, float amp, void *out, hipStream_t s)
+{
+    if (n_total <= 0) return hipSuccess;
+    int64_t nb = (n_total + 255) / 256;
+    if (nb > 65536) nb = 65536;
+    if (i16) hipLaunchKernelGGL(synth_stream_kernel<true>, dim3((unsigned)nb), dim3(256), 0, s, seed, n_total, sps, taps, M,
+                                sigma, cfo, tau0, drift, amp, out);
+    else hipLaunchKernelGGL(synth_stream_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, seed, n_total, sps, taps, M,
+                            sigma, cfo, tau0, drift, amp, out);
+    return hipGetLastError();
+}
 
 hipError_t launch_synth(uint64_t seed, int64_t b0, int B, int n_sym, int sps, const double *taps, int M,
                         float sigma, void *out, hipStream_t s)

@@ -14,7 +14,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import FirArgs, SyncArgs, check
+from ._lib import CaptureArgs, FirArgs, SyncArgs, check, DSP_C64, DSP_I16
 from .api import rrc_filter
 
 _OUT_ELEM = {"rec": 8, "err": 4, "mu": 4, "sig": 8, "freq": 4, "ef": 4, "dec": 1}
@@ -153,3 +153,74 @@ class BurstPipeline:
         """The matched-filtered complex64 bursts the recurrence kernel consumed."""
         b_hi = self.B if b_hi is None else b_hi
         return self.fetch_tiles(self.d_tiles, 8, self.rows, np.complex64, b_lo, b_hi, self.N)
+
+
+class CapturePipeline:
+    """One long capture resident in HBM -> segment-parallel receiver (north-star (c)).
+
+    generate() synthesises a continuous QPSK stream on the device (int16 I,Q by default, the
+    wire format of hw1/gardner.py:77-91); run() = peak normalisation, RRC 'same' / std of the
+    whole stream, batched Gardner + FLL over overlapping segment windows, stitching; the
+    decisions (and mu / frequency per symbol) stay on the device until fetch()."""
+
+    def __init__(self, ctx, n_samples, sps=4, span=10, rolloff=0.35, alpha=0.007, mu0=0.0, Bn=0.003,
+                 y=1.0, seg_len=65536, warmup=4096, int16=True, matched_filter=True, want_mu=True,
+                 want_freq=False):
+        self.ctx, self.L = ctx, _lib.lib()
+        self.n, self.sps = int(n_samples), int(sps)
+        self.kind = DSP_I16 if int16 else DSP_C64
+        self.taps = rrc_filter(sps, span, rolloff)
+        self.S = int(self.L.dsp_capture_segments(self.n, int(seg_len)))
+        self.cap = self.n // self.sps + 8 * self.S + 64
+        self._bufs = []
+        self.d_taps = self._alloc(self.taps.nbytes)
+        ctx.h2d(self.d_taps, self.taps)
+        self.d_x = self._alloc(self.n * (4 if int16 else 8))
+        self.d_dec = self._alloc(self.cap)
+        self.d_mu = self._alloc(self.cap * 4) if want_mu else None
+        self.d_freq = self._alloc(self.cap * 4) if want_freq else None
+        self.total = C.c_int64(0)
+        self.info = np.zeros((self.S, 4), np.int32)
+        a = CaptureArgs()
+        a.x = self.d_x; a.in_kind = self.kind; a.normalize = 1; a.n_samples = self.n
+        if matched_filter:
+            a.h = self.d_taps; a.n_taps = self.taps.size
+        a.sps = self.sps; a.alpha = alpha; a.mu0 = mu0; a.Bn = Bn; a.y = y
+        a.seg_len = int(seg_len); a.warmup = int(warmup)
+        a.dec = self.d_dec; a.mu = self.d_mu; a.freq = self.d_freq; a.capacity = self.cap
+        a.n_symbols = C.addressof(self.total); a.seg_info = self.info.ctypes.data
+        self._args = a
+
+    def _alloc(self, n):
+        p = self.ctx.malloc(n)
+        self._bufs.append(p)
+        return p
+
+    def close(self):
+        for p in self._bufs:
+            self.ctx.free(p)
+        self._bufs = []
+
+    def generate(self, seed=20251114, esn0_db=20.0, cfo=1.5e-4, tau0=0.3, drift=0.0, amplitude=6000.0):
+        check(self.L.dsp_synth_stream_dev(self.ctx.handle, C.c_uint64(seed), self.n, self.sps,
+                                          C.c_void_p(self.d_taps), self.taps.size, float(esn0_db), float(cfo),
+                                          float(tau0), float(drift), self.kind, float(amplitude),
+                                          C.c_void_p(self.d_x)))
+
+    def upload(self, x):
+        x = np.ascontiguousarray(x, dtype=np.int16 if self.kind == DSP_I16 else np.complex64)
+        assert x.nbytes == self.n * (4 if self.kind == DSP_I16 else 8)
+        self.ctx.h2d(self.d_x, x)
+
+    def run(self):
+        """The whole segmented receiver; synchronises; returns the number of symbols."""
+        check(self.L.dsp_sync_capture_segmented_dev(self.ctx.handle, C.byref(self._args)))
+        return int(self.total.value)
+
+    def fetch(self, name="dec", lo=0, hi=None):
+        hi = int(self.total.value) if hi is None else hi
+        d, dt = {"dec": (self.d_dec, np.uint8), "mu": (self.d_mu, np.float32),
+                 "freq": (self.d_freq, np.float32)}[name]
+        out = np.empty(hi - lo, dt)
+        self.ctx.d2h(out, d + lo * out.itemsize)
+        return out

@@ -90,3 +90,13 @@ def device_params(seed: int, b: int):
         h = _splitmix64(key + (np.uint64(2) << np.uint64(40)) + np.arange(3, dtype=np.uint64))
     u = ((h >> np.uint64(11)).astype(np.float64) + 1.0) / 9007199254740992.0
     return u[0] - 0.5, (u[1] - 0.5) * 1e-3, u[2] * 2 * np.pi
+
+
+def stream_symbols(seed: int, i0: int, count: int) -> np.ndarray:
+    """Quadrant indices of symbols i0 .. i0+count-1 of the continuous stream dsp_synth_stream_dev
+    generates (symbol i sits on sample i*sps of the transmit grid)."""
+    with np.errstate(over="ignore"):
+        key = _splitmix64(np.uint64(seed))
+        idx = np.arange(i0, i0 + count, dtype=np.uint64)
+        h = _splitmix64(key + (np.uint64(1) << np.uint64(40)) + idx)
+    return (h & np.uint64(3)).astype(np.uint8)

@@ -163,6 +163,8 @@ typedef struct dsp_sync_args {
     int64_t out_rows;       /* rows of every output; the LAST row is scratch: capacity = out_rows-1 */
     int32_t *n_out;         /* [B] or NULL                                           */
     int32_t *status;        /* [B] or NULL; bit0 = capacity reached                  */
+    void *pos;              /* tiles or NULL: sample position k+mu of recovered symbol r+1 in row r
+                               (gardner2.py:95; float32 / float64 like mu)              */
 } dsp_sync_args;
 
 typedef struct dsp_fir_args {
@@ -233,6 +235,15 @@ int64_t dsp_capture_segments(int64_t n_samples, int64_t seg_len);   /* S = ceil(
  * numpy-random based); asynchronous; B <= 65535 per call.                          */
 int dsp_synth_bursts_dev(dsp_ctx *ctx, uint64_t seed, int64_t b0, int64_t B, int n_sym, int sps,
                          const double *d_taps, int n_taps, double esn0_db, void *d_out_c64);
+
+/* One continuous synthetic QPSK stream on the device (config 5: a long capture for the
+ * segment-parallel mode): same recipe, timing offset tau0 + drift*n samples, carrier offset cfo
+ * cycles/sample; out_kind DSP_I16 (interleaved int16 I,Q, `amplitude` counts per unit) or
+ * DSP_C64.  Symbol i is splitmix-derived from seed (dsp_amd/synth.py stream_symbols).
+ * No counterpart in the reference; asynchronous.                                  */
+int dsp_synth_stream_dev(dsp_ctx *ctx, uint64_t seed, int64_t n_samples, int sps, const double *d_taps,
+                         int n_taps, double esn0_db, double cfo, double tau0, double drift, int out_kind,
+                         double amplitude, void *d_out);
 
 /* Launches the fused recurrence kernel on the context stream (asynchronous).    */
 int dsp_sync_tiles_dev(dsp_ctx *ctx, const dsp_sync_args *args);

@@ -230,19 +230,21 @@ _TURN = np.array([1, 3, 0, 2], np.uint8)        # quadrant index after +90 degre
 
 def _positions(start, mu, n, sps):
     """Stream position of symbol rows 0..n-1 of a window: row 0 is the window's first sample
-    (gardner2.py:59), row r >= 1 is k + mu with k = sps*(r + slips) (gardner2.py:61,65-70,95,98);
-    a slip shows as a jump of -+sps in the float32 mu history."""
+    (gardner2.py:59), row r >= 1 is k + mu of the iteration that produced it (gardner2.py:95)
+    with k = sps*(r + slips) (gardner2.py:61,65-70,98; a slip shows as a jump of -+sps in the mu
+    history), rounded to float32 as the device stores it."""
     p = np.empty(n)
     p[0] = start
     if n > 1:
-        m = mu[:n - 1].astype(np.float32)
+        m = np.asarray(mu[:n - 1], dtype=np.float64)
         d = np.diff(m)
         step = np.zeros(n - 1, np.int64)
-        step[1:][d < np.float32(-0.5 * sps)] = 1
-        step[1:][d > np.float32(0.5 * sps)] = -1
+        step[1:][d < -0.5 * sps] = 1
+        step[1:][d > 0.5 * sps] = -1
         slips = np.cumsum(step)
         r = np.arange(1, n)
-        p[1:] = start + sps * (r + slips).astype(np.float64) + m.astype(np.float64)
+        local = (sps * (r + slips).astype(np.float64) + m).astype(np.float32)
+        p[1:] = start + local.astype(np.float64)
     return p
 
 

@@ -104,3 +104,27 @@ def test_gpu_segmented_int16_with_matched_filter(oracle, stream, ctx):
     assert np.max(np.abs(got["mu"] - ref["mu"])) < 1e-3
     n = min(got["n"], q.size)
     assert best_rotation_match(got["dec"][500:n], q[500:n]) > 0.999
+
+
+@pytest.mark.gpu
+def test_gpu_capture_pipeline_device_generated(ctx):
+    """2^24-sample int16 capture generated on the device (config 5 scaled down): symbol count and
+    decisions against the transmitted symbols, aligned by the stitched positions; a drift large
+    enough to make the timing loop slip symbols."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    from bench_capture import check_decisions, SEED
+    from dsp_amd.pipeline import CapturePipeline
+    n, sps = 1 << 24, 4
+    for drift in (0.0, 1.0e-6):                 # 1e-6 * 2^24 = 16.8 samples = 4 symbol slips
+        pipe = CapturePipeline(ctx, n, sps, seg_len=65536, warmup=4096)
+        pipe.generate(SEED, tau0=0.3, drift=drift)
+        nsym = pipe.run()
+        rate, nslip = check_decisions(pipe, n // sps, 0.3, drift, sps, 0, nsym - 8)
+        assert abs(nsym - n // sps) <= 4 + nslip
+        assert (nslip >= 3) == (drift > 0)
+        assert rate > 0.999, (drift, rate)
+        info = pipe.info
+        assert (info[1:, 0] > 4000).all() and (info[:, 1] > info[:, 0]).all()
+        pipe.close()
