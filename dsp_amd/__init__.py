@@ -12,7 +12,8 @@ from ._lib import (Context, DspError, default_context, build, lib, LIB_PATH,  # 
 from .api import (rrc_filter, fll_gains, interpolate_sample, gardner_timing_recovery,  # noqa: F401
                   gardner_ted, fll_func, gardner_batch, fll_batch, sync_chain_batch,
                   read_iq_int16, read_iq_int16_words, read_iq_float32, fir_batch, filter_samples,
-                  rx_chain_batch, sync_capture_segmented)
+                  rx_chain_batch, sync_capture_segmented, lagrange_resample,
+                  apply_fractional_shift)
 
 __all__ = [
     "Context", "DspError", "default_context", "build", "lib",
@@ -20,5 +21,5 @@ __all__ = [
     "gardner_timing_recovery", "gardner_ted", "fll_func",
     "gardner_batch", "fll_batch", "sync_chain_batch",
     "read_iq_int16", "read_iq_int16_words", "read_iq_float32", "fir_batch", "filter_samples",
-    "rx_chain_batch", "sync_capture_segmented",
+    "rx_chain_batch", "sync_capture_segmented", "lagrange_resample", "apply_fractional_shift",
 ]

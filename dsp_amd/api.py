@@ -386,3 +386,30 @@ def sync_capture_segmented(x, sps=4, alpha=0.007, mu_initial=0.0, Bn=0.003, y=1,
     if freq is not None:
         out["freq"] = freq[:nn]
     return out
+
+
+def lagrange_resample(signal, positions, half_len=4, *, ctx=None):
+    """hw1/test_lagrange_resampling.py:34-72: resample `signal` at fractional `positions` with a
+    (2*half_len+1)-point Lagrange interpolator; returns the dtype of `signal`."""
+    ctx = ctx or default_context()
+    sig = np.asarray(signal)
+    pos = np.ascontiguousarray(positions, dtype=np.float64).ravel()
+    if sig.ndim != 1 or sig.size == 0:
+        raise ValueError("signal must be a non-empty 1-D array")
+    cplx = np.iscomplexobj(sig)
+    if sig.dtype == np.complex64:
+        x, dt = np.ascontiguousarray(sig), DSP_C64
+    else:
+        x, dt = np.ascontiguousarray(sig, dtype=np.complex128), DSP_C128
+    out = np.empty(pos.size, np.complex128)
+    check(_lib.lib().dsp_lagrange_resample(ctx.handle, _vp(x), dt, x.size, _vp(pos), pos.size, int(half_len),
+                                           _vp(out)))
+    if cplx:
+        return out.astype(sig.dtype)
+    return out.real.astype(sig.dtype if sig.dtype.kind == "f" else np.float64)
+
+
+def apply_fractional_shift(signal, shift, half_len=4, *, ctx=None):
+    """hw1/test_lagrange_resampling.py:75-79."""
+    positions = np.arange(len(signal), dtype=float) + shift
+    return lagrange_resample(signal, positions, half_len, ctx=ctx)

@@ -759,6 +759,28 @@ int dsp_rx_chain(dsp_ctx *c, const void *x, int in_kind, int64_t B, int64_t N, i
                         ef, dec, n_out, out_stride);
 }
 
+// lagrange_resample -- hw1/test_lagrange_resampling.py:34-72
+int dsp_lagrange_resample(dsp_ctx *c, const void *x, int dtype, int64_t n, const double *positions, int64_t P,
+                          int half_len, double *out_c128)
+{
+    if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    if (dtype != DSP_C64 && dtype != DSP_C128) return fail(DSP_E_ARG, "lagrange: dtype must be DSP_C64 or DSP_C128");
+    if (n < 1 || n >= (1LL << 31)) return fail(DSP_E_ARG, "lagrange: signal length out of range");
+    if (half_len < 1 || half_len > 8) return fail(DSP_E_ARG, "lagrange: half_len must be in [1,8]");
+    if (P < 0 || (P && (!x || !positions || !out_c128))) return fail(DSP_E_ARG, "lagrange: NULL argument");
+    if (P == 0) return DSP_OK;
+    const size_t eb = dtype == DSP_C128 ? 16 : 8;
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf d_x, d_p, d_o;
+    HIP_TRY(d_x.alloc((size_t)n * eb)); HIP_TRY(d_p.alloc((size_t)P * 8)); HIP_TRY(d_o.alloc((size_t)P * 16));
+    HIP_TRY(hipMemcpyAsync(d_x.p, x, (size_t)n * eb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_p.p, positions, (size_t)P * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_lagrange_resample(d_x.p, dtype == DSP_C128, (int)n, d_p.as<double>(), P, half_len, d_o.p, c->stream));
+    HIP_TRY(hipMemcpyAsync(out_c128, d_o.p, (size_t)P * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DSP_OK;
+}
+
 // ---------------------------------------------------------------------------
 // Segment-parallel mode (segment_kernels.hip)
 int64_t dsp_capture_segments(int64_t n_samples, int64_t seg_len)

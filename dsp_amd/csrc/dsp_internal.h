@@ -131,3 +131,5 @@ hipError_t launch_seg_windows(int S, int64_t n_total, int64_t seg_len, int64_t l
 hipError_t launch_seg_stitch(const SegParams &P, int overlap_vote, hipStream_t s);
 hipError_t launch_seg_gather(const SegParams &P, uint8_t *dec_out, float *mu_out, float *freq_out,
                              int64_t capacity, hipStream_t s);
+hipError_t launch_lagrange_resample(const void *x, int c128, int len, const double *pos, int64_t P, int half_len,
+                                    void *out, hipStream_t s);

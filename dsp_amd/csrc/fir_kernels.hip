@@ -40,8 +40,9 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
     typedef typename Stage<IN>::T ST;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int M = P.M, CH = P.CH, W = P.W, stride = P.stride;
-    double *hrev = (double *)smem;                                  // [M] reversed taps
-    ST *xs = (ST *)(smem + (((size_t)M * 8 + 15) & ~(size_t)15));  // [64][stride]
+    const int m8 = (M + 7) & ~7;
+    double *hrev = (double *)smem;                                  // [m8] reversed taps, zero padded
+    ST *xs = (ST *)(smem + (size_t)m8 * 8);                         // [64][stride]
     double *red = (double *)xs;                                     // [4][64][4] reduction scratch, reuses xs
 
     const int tile = blockIdx.y, chunk = blockIdx.x;
@@ -49,30 +50,46 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float isc = P.in_scale ? *P.in_scale : 1.0f;
 
-    for (int i = threadIdx.x; i < M; i += 256) hrev[i] = P.h[M - 1 - i];
-    // stage the input windows: xs[bb][i] = x[b][n0 + start - (M-1) + i], zero outside the burst
+    for (int i = threadIdx.x; i < m8; i += 256) hrev[i] = i < M ? P.h[M - 1 - i] : 0.0;
+    // stage the input windows: xs[bb][i] = x[b][n0 + start - (M-1) + i], zero outside the burst.
+    // W < 128 (fir_plan), so a wave covers a row in two steps; all 32 loads of a wave are issued
+    // before the first LDS write (each wave would otherwise pay the HBM latency 32 times in a row).
     const int x0 = n0 + P.start - (M - 1);
-    for (int q = 0; q < 16; q++) {
-        const int bb = w * 16 + q;
-        const int b = tile * 64 + bb;
-        const int len = b < P.B ? (P.lens ? P.lens[b] : P.len_all) : 0;
-        if (P.starts) {         // window of one long stream: true neighbours across the window edges
-            const int64_t st = b < P.B ? P.starts[b] : 0;
-            const IN *src = (const IN *)P.src;
-            for (int i = lane; i < W; i += 64) {
-                const int64_t g = st + x0 + i;
-                ST v = ST{0, 0};
-                if (b < P.B && g >= 0 && g < P.n_total) v = to_stage(src[g], isc);
-                xs[(size_t)bb * stride + i] = v;
+    {
+        IN v[16][2];
+        bool ok[16][2];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int b = tile * 64 + w * 16 + q;
+            const bool live = b < P.B;
+            if (P.starts) {         // window of one long stream: true neighbours across the window edges
+                const int64_t st = live ? P.starts[b] : 0;
+                const IN *src = (const IN *)P.src;
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const int i = lane + 64 * k;
+                    const int64_t g = st + x0 + i;
+                    ok[q][k] = live && i < W && g >= 0 && g < P.n_total;
+                    v[q][k] = src[ok[q][k] ? g : 0];
+                }
+            } else {
+                const int len = live ? (P.lens ? P.lens[b] : P.len_all) : 0;
+                const IN *src = (const IN *)P.src + (int64_t)(live ? b : 0) * P.ld;
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const int i = lane + 64 * k, n = x0 + i;
+                    ok[q][k] = i < W && n >= 0 && n < len;
+                    v[q][k] = src[ok[q][k] ? n : 0];
+                }
             }
-            continue;
         }
-        const IN *src = (const IN *)P.src + (int64_t)b * P.ld;
-        for (int i = lane; i < W; i += 64) {
-            const int n = x0 + i;
-            ST v = ST{0, 0};
-            if (n >= 0 && n < len) v = to_stage(src[n], isc);
-            xs[(size_t)bb * stride + i] = v;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int i = lane + 64 * k;
+                if (i < W) xs[(size_t)(w * 16 + q) * stride + i] = ok[q][k] ? to_stage(v[q][k], isc) : ST{0, 0};
+            }
         }
     }
     __syncthreads();
@@ -101,7 +118,7 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
                 for (int j = 0; j < OG + 7; j++) xw[j] = xrow[o0 + i0 + j];
 #pragma unroll
                 for (int ii = 0; ii < 8; ii++) {
-                    const double hv = (i0 + ii < M) ? hrev[i0 + ii] : 0.0;
+                    const double hv = hrev[i0 + ii];
 #pragma unroll
                     for (int o = 0; o < OG; o++) {
                         are[o] = __builtin_fma(hv, (double)xw[o + ii].x, are[o]);
@@ -359,7 +376,7 @@ hipError_t launch_fir_tile_t(const FirParams &P, hipStream_t s)
     const int nchunk = P.nchunk, ntiles = (P.B + 63) / 64;
     size_t xs_bytes = (size_t)64 * P.stride * sizeof(typename Stage<IN>::T);
     if (xs_bytes < (size_t)4 * 64 * 4 * 8) xs_bytes = (size_t)4 * 64 * 4 * 8;
-    size_t lds = (((size_t)P.M * 8 + 15) & ~(size_t)15) + xs_bytes;
+    size_t lds = (size_t)((P.M + 7) & ~7) * 8 + xs_bytes;
     hipLaunchKernelGGL((fir_tile_kernel<IN, OUT, OG>), dim3(nchunk, ntiles), dim3(256), lds, s, P);
     return hipGetLastError();
 }
@@ -372,9 +389,10 @@ bool fir_plan(int in_kind, int M, int n_out, FirParams &P)
     const int elem = in_kind == DSP_IN_C128 ? 16 : 8;
     const int og = in_kind == DSP_IN_C128 ? 4 : 8;
     if (M > 4096) return false;
-    const size_t budget = 64 * 1024 - (((size_t)M * 8 + 15) & ~(size_t)15);
     const int m8 = (M + 7) & ~7;
+    const size_t budget = 64 * 1024 - (size_t)m8 * 8;
     int best = 0;
+    // CH / 4 outputs per wave, a whole number of og-output register blocks
     for (int CH = 128; CH >= 4 * og; CH -= 4 * og) {
         int W = CH + m8 - 1;               // highest staged index read: CH + ceil8(M) - 2
         int stride = W | 1;

@@ -21,6 +21,9 @@
 // There is no reference counterpart; the oracle restates the same
 // definition on the CPU (oracle/oracle.py sync_capture_segmented).
 #include "dsp_internal.h"
+#include "sync_lane.h"
+
+#pragma clang fp contract(off)
 
 namespace {
 
@@ -180,7 +183,43 @@ __global__ __launch_bounds__(256) void seg_gather_k(SegParams P, uint8_t *__rest
     }
 }
 
+// lagrange_resample(signal, positions, half_len) -- hw1/test_lagrange_resampling.py:34-72:
+// one thread per position, the (2h+1)-point barycentric form with the reference's index
+// clipping and exact-node shortcut (sync_lane.h lagrange_at, the interpolator the timing loop
+// uses when interp_half_len > 0).
+template <typename T>
+struct VecFetch {
+    const T *x;
+    __device__ __forceinline__ dspm::cd operator()(int i) const
+    {
+        dspm::cd z; z.re = (double)x[i].x; z.im = (double)x[i].y; return z;
+    }
+};
+template <typename T>
+__global__ void lagrange_resample_k(const T *__restrict__ x, int len, const double *__restrict__ pos,
+                                    int64_t P, int half_len, double2 *__restrict__ out)
+{
+    const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    dspm::LagrangeW L;
+    dspm::lagrange_weights(half_len, L);
+    dspm::cd z = dspm::lagrange_at(pos[p], len, L, VecFetch<T>{x});
+    out[p] = make_double2(z.re, z.im);
+}
+
 }  // namespace
+
+hipError_t launch_lagrange_resample(const void *x, int c128, int len, const double *pos, int64_t P, int half_len,
+                                    void *out, hipStream_t s)
+{
+    if (P <= 0) return hipSuccess;
+    const unsigned nb = (unsigned)((P + 255) / 256);
+    if (c128) hipLaunchKernelGGL(lagrange_resample_k<double2>, dim3(nb), dim3(256), 0, s, (const double2 *)x, len, pos, P,
+                                 half_len, (double2 *)out);
+    else hipLaunchKernelGGL(lagrange_resample_k<float2>, dim3(nb), dim3(256), 0, s, (const float2 *)x, len, pos, P,
+                            half_len, (double2 *)out);
+    return hipGetLastError();
+}
 
 hipError_t launch_seg_windows(int S, int64_t n_total, int64_t seg_len, int64_t lead, int64_t tail,
                               int64_t *starts, int *lens, hipStream_t s)

@@ -190,6 +190,13 @@ int64_t dsp_fir_workspace_bytes(int in_kind, int64_t B, int64_t N, int n_taps);
  * Returns DSP_E_ARG if the filter is too long for the LDS-tiled kernel (n_taps > ~80). */
 int dsp_fir_tiles_dev(dsp_ctx *ctx, const dsp_fir_args *args);
 
+/* lagrange_resample(signal, positions, half_len=4) -- hw1/test_lagrange_resampling.py:34-72
+ * ((2h+1)-point barycentric Lagrange, neighbour indices clipped to [0, n-1] :58-59, exact-node
+ * shortcut :62-66).  x: n samples of dtype DSP_C64 / DSP_C128 (a real signal is passed with zero
+ * imaginary parts); out: P complex128 values.  Host pointers.                              */
+int dsp_lagrange_resample(dsp_ctx *ctx, const void *x, int dtype, int64_t n, const double *positions, int64_t P,
+                          int half_len, double *out_c128);
+
 /* ---- segment-parallel mode for ONE long capture (north-star (c)) ----------
  * No counterpart in the reference, whose loops are strictly sequential (gardner2.py:63-98,
  * fll_func.py:14-26).  The capture is cut into segments of seg_len samples; each segment is one
