@@ -12,7 +12,7 @@ prof, out = sys.argv[1], sys.argv[2]
 want = sys.argv[3] if len(sys.argv) > 3 else "sync_"
 summary = {"source": os.path.basename(prof.rstrip("/")), "kernel_filter": want}
 
-ks = glob.glob(os.path.join(prof, "kt", "*", "*_kernel_stats.csv"))
+ks = glob.glob(os.path.join(prof, "kt", "**", "*kernel_stats.csv"), recursive=True)
 if ks:
     rows = list(csv.DictReader(open(ks[0])))
     summary["kernel_stats"] = [
@@ -24,7 +24,7 @@ pmc = {}
 for d in sorted(glob.glob(os.path.join(prof, "pmc_*"))):
     if not os.path.isdir(d):
         continue
-    f = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     if not f:
         continue
     agg = collections.defaultdict(list)
@@ -48,7 +48,23 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         "total_bytes_corrected": 2 * fetch_kib * 1024 + write_kib * 1024,
         "note": "reads are 16 B/lane LDS-DMA streams (x2 correction applies); the stores are 4/8/1 "
                 "B per lane (WRITE_SIZE calibrated only for 16 B/lane: treat as indicative)"}
+bl = os.path.join(prof, "bench_line.json")
+if os.path.exists(bl):
+    try:
+        summary["bench_line"] = json.load(open(bl))
+    except ValueError:
+        pass
 json.dump(summary, open(out + ".json", "w"), indent=1)
+if "hbm_traffic" in summary and "bench_line" in summary:
+    cfg = summary["bench_line"]["config"]
+    json.dump({"kernel": summary["bench_line"]["roofline"]["kernel"],
+               "bursts_per_gpu": cfg["bursts_per_gpu"], "samples_per_burst": cfg["samples_per_burst"],
+               "hbm_bytes_per_launch": summary["hbm_traffic"]["total_bytes_corrected"],
+               "fetch_bytes_corrected": summary["hbm_traffic"]["fetch_bytes_corrected"],
+               "write_bytes": summary["hbm_traffic"]["write_bytes"],
+               "source": os.path.basename(out) + ".json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                         "FETCH_SIZE x2 per MI355X_MICROARCH.md HBM section)"},
+              open(os.path.join(os.path.dirname(out) or ".", "traffic.json"), "w"), indent=1)
 with open(out + ".txt", "w") as fh:
     for r in summary.get("kernel_stats", []):
         fh.write(f"{r['avg_us']:12.1f} us avg  {r['calls']:5d} calls  {r['pct']:6.2f}%  {r['name'][:110]}\n")
