@@ -123,6 +123,20 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
+    # same-box reference: a plain float4 copy of the input tiles (1:1 read/write stream)
+    copy_gbps = None
+    nb = pipe.ntiles * pipe.rows * 64 * 8
+    d_tmp = ctx.malloc(nb)
+    try:
+        ctx.stream_copy(d_tmp, pipe.d_tiles, nb)
+        ctx.synchronize()
+        ctx.timer_start()
+        for _ in range(5):
+            ctx.stream_copy(d_tmp, pipe.d_tiles, nb)
+        copy_gbps = 2.0 * nb * 5 / (ctx.timer_stop() * 1e-3) / 1e9
+    finally:
+        ctx.free(d_tmp)
+
     for _ in range(args.warmup):
         step()
     barrier()
@@ -182,7 +196,8 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic,
                      "kernel": "sync_split_kernel<c64,gardner2>" if args.split != 0 else "sync_kernel<c64,gardner2,fll>", "kernel_ms": kern_ms,
-                     "bytes_per_sample": A_FULL},
+                     "bytes_per_sample": A_FULL,
+                     "same_box_float4_copy_GBps": copy_gbps},
     }
     if rank == 0:
         if not args.no_cpu and world == 1:

@@ -111,6 +111,8 @@ def _declare(L):
     L.dsp_memset.argtypes = [vp, vp, ci, C.c_size_t]
     L.dsp_h2d.argtypes = [vp, vp, vp, C.c_size_t]
     L.dsp_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+    L.dsp_stream_copy_dev.argtypes = [vp, vp, vp, C.c_size_t]
+    L.dsp_stream_copy_dev.restype = ci
     L.dsp_timer_start.argtypes = [vp]
     L.dsp_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
     L.dsp_rrc_taps.argtypes = [ci, ci, dbl, vp, i64]
@@ -213,6 +215,9 @@ class Context:
 
     def d2h(self, arr, dptr):
         check(lib().dsp_d2h(self.handle, arr.ctypes.data_as(C.c_void_p), C.c_void_p(dptr), arr.nbytes))
+
+    def stream_copy(self, d_dst, d_src, nbytes):
+        check(lib().dsp_stream_copy_dev(self.handle, C.c_void_p(d_dst), C.c_void_p(d_src), int(nbytes)))
 
     def timer_start(self):
         check(lib().dsp_timer_start(self.handle))

@@ -188,6 +188,14 @@ int dsp_d2h(dsp_ctx *c, void *hptr, const void *dptr, size_t bytes)
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DSP_OK;
 }
+int dsp_stream_copy_dev(dsp_ctx *c, void *d_dst, const void *d_src, size_t bytes)
+{
+    if (!c || !d_dst || !d_src) return fail(DSP_E_ARG, "copy: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_stream_copy(d_src, d_dst, bytes, c->stream));
+    return DSP_OK;
+}
+
 int dsp_timer_start(dsp_ctx *c)
 {
     if (!c) return fail(DSP_E_ARG, "ctx is NULL");

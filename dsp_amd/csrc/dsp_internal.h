@@ -133,3 +133,4 @@ hipError_t launch_seg_gather(const SegParams &P, uint8_t *dec_out, float *mu_out
                              int64_t capacity, hipStream_t s);
 hipError_t launch_lagrange_resample(const void *x, int c128, int len, const double *pos, int64_t P, int half_len,
                                     void *out, hipStream_t s);
+hipError_t launch_stream_copy(const void *src, void *dst, size_t bytes, hipStream_t s);

@@ -64,7 +64,22 @@ __global__ __launch_bounds__(256) void bursts_from_tiles_k(const E *__restrict__
     }
 }
 
+// plain streaming copy, 16 B per thread and step (bench.py measures it beside the kernels: what
+// the memory system of THIS box gives a 1:1 read/write stream)
+typedef float f4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void stream_copy_k(const f4v *__restrict__ a, f4v *__restrict__ b, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) b[i] = a[i];
+}
+
 }  // namespace
+
+hipError_t launch_stream_copy(const void *src, void *dst, size_t bytes, hipStream_t s)
+{
+    if (bytes < 16) return hipSuccess;
+    hipLaunchKernelGGL(stream_copy_k, dim3(32768), dim3(256), 0, s, (const f4v *)src, (f4v *)dst, bytes / 16);
+    return hipGetLastError();
+}
 
 hipError_t launch_tile_from_bursts(const void *src, int64_t ld, const int *lens, int len_all, int B,
                                    void *dst, int rows, int elem_bytes, hipStream_t stream,

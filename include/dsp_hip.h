@@ -57,6 +57,9 @@ int dsp_free(dsp_ctx *ctx, void *dptr);
 int dsp_memset(dsp_ctx *ctx, void *dptr, int value, size_t bytes);
 int dsp_h2d(dsp_ctx *ctx, void *dptr, const void *hptr, size_t bytes);
 int dsp_d2h(dsp_ctx *ctx, void *hptr, const void *dptr, size_t bytes);
+/* plain float4 streaming copy kernel (asynchronous; bytes rounded down to 16): bench.py times it
+ * beside the kernels as the same-box reference for a 1:1 read/write stream.  Utility. */
+int dsp_stream_copy_dev(dsp_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
 int dsp_timer_start(dsp_ctx *ctx);                       /* hipEvent on the context stream */
 int dsp_timer_stop(dsp_ctx *ctx, float *elapsed_ms);     /* records, synchronises, returns */
 

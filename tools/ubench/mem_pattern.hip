@@ -30,7 +30,7 @@ __global__ __launch_bounds__(128) void k(const uint8_t *x, uint8_t *rec, uint8_t
         int F = 0;   // pieces (1 KiB = 2 rows) issued
         for (int it0 = 0; it0 < n_sym; it0 += T) {
             if (mode & 1) {
-                if (mode & 2) { if (var & 4) waitv<6>(); else waitv<18>(); } else waitv<0>();
+                if ((mode & 2) && !(var & 24)) { if (var & 4) waitv<6>(); else waitv<18>(); } else if (var & 24) waitv<8>(); else waitv<0>();
                 for (int p = 0; p < 2 * T; p += 4, F += 4) {   // 2T pieces per block of T symbols (4 rows each)
                     const uint8_t *g = xt + (size_t)F * 1024;
                     unsigned off = lds_base + (unsigned)((F & 31) * 1024);
@@ -47,6 +47,27 @@ __global__ __launch_bounds__(128) void k(const uint8_t *x, uint8_t *rec, uint8_t
             for (int t = 0; t < T; t++) {
                 const int it = it0 + t;
                 for (int s = 0; s < spin; s++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(acc));
+                if ((mode & 2) && (var & 24)) {
+                    if ((it & 3) == 3) {
+                        const int r0 = it - 3;
+                        if (var & 16) {      // packed: 4 symbols per lane contiguous
+                            f4v w = {acc, acc, acc, acc};
+                            unsigned oa = lane * 32 + (r0 >> 2) * 2048, ob = lane * 16 + (r0 >> 2) * 1024;
+                            asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(oa), "v"(w), "s"(rt) : "memory");
+                            asm volatile("global_store_dwordx4 %0, %1, %2 offset:16" :: "v"(oa), "v"(w), "s"(rt) : "memory");
+                            asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(ob), "v"(w), "s"(et) : "memory");
+                            asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(ob), "v"(w), "s"(mt) : "memory");
+                        } else {
+                            for (int q = 0; q < 4; q++) {
+                                f2v v = {acc, acc};
+                                unsigned o8 = lane * 8 + (r0 + q + 1) * 512, o4 = lane * 4 + (r0 + q) * 256;
+                                asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(o8), "v"(v), "s"(rt) : "memory");
+                                asm volatile("global_store_dword %0, %1, %2" :: "v"(o4), "v"(acc), "s"(et) : "memory");
+                                asm volatile("global_store_dword %0, %1, %2" :: "v"(o4), "v"(acc), "s"(mt) : "memory");
+                            }
+                        }
+                    }
+                } else
                 if (mode & 2) {
                     f2v v = {acc, acc};
                     unsigned o8 = lane * 8 + (it + 1) * 512, o4 = lane * 4 + it * 256;
@@ -72,6 +93,30 @@ __global__ __launch_bounds__(128) void k(const uint8_t *x, uint8_t *rec, uint8_t
                       *et = ef + (size_t)tile * out_rows * 256, *dt = dec + (size_t)tile * out_rows * 64;
         for (int it = 0; it < n_sym; it++) {
             for (int s = 0; s < spin; s++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(acc));
+            if ((mode & 4) && (var & 24)) {
+                if ((it & 3) == 3) {
+                    const int r0 = it - 3;
+                    unsigned q = lane & 3;
+                    if (var & 16) {
+                        f4v w = {acc, acc, acc, acc};
+                        unsigned oa = lane * 32 + (r0 >> 2) * 2048, ob = lane * 16 + (r0 >> 2) * 1024, oc = lane * 4 + (r0 >> 2) * 256;
+                        asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(oa), "v"(w), "s"(st) : "memory");
+                        asm volatile("global_store_dwordx4 %0, %1, %2 offset:16" :: "v"(oa), "v"(w), "s"(st) : "memory");
+                        asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(ob), "v"(w), "s"(ft) : "memory");
+                        asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(ob), "v"(w), "s"(et) : "memory");
+                        asm volatile("global_store_dword %0, %1, %2" :: "v"(oc), "v"(q), "s"(dt) : "memory");
+                    } else {
+                        for (int k = 0; k < 4; k++) {
+                            f2v v = {acc, acc};
+                            unsigned o8 = lane * 8 + (r0 + k + 1) * 512, o4 = lane * 4 + (r0 + k + 1) * 256, o1 = lane + (r0 + k + 1) * 64;
+                            asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(o8), "v"(v), "s"(st) : "memory");
+                            asm volatile("global_store_dword %0, %1, %2" :: "v"(o4), "v"(acc), "s"(ft) : "memory");
+                            asm volatile("global_store_dword %0, %1, %2" :: "v"(o4), "v"(acc), "s"(et) : "memory");
+                            asm volatile("global_store_byte %0, %1, %2" :: "v"(o1), "v"(q), "s"(dt) : "memory");
+                        }
+                    }
+                }
+            } else
             if (mode & 4) {
                 f2v v = {acc, acc};
                 unsigned o8 = lane * 8 + (it + 1) * 512, o4 = lane * 4 + (it + 1) * 256, o1 = lane + (it + 1) * 64;
@@ -104,6 +149,12 @@ __global__ __launch_bounds__(128) void k(const uint8_t *x, uint8_t *rec, uint8_t
     if (acc == 12345.678f) dec[0] = 1;
 }
 
+// plain streaming copy for comparison: every thread moves 16 B per step, grid-stride
+__global__ __launch_bounds__(256) void copy_k(const f4v *__restrict__ a, f4v *__restrict__ b, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) b[i] = a[i];
+}
+
 int main(int argc, char **argv)
 {
     const int B = argc > 1 ? atoi(argv[1]) : 65536;
@@ -120,7 +171,23 @@ int main(int argc, char **argv)
     const int lds = 40960;
     const double bytes_r = (double)B * 8192 * 8, bytes_g = (double)B * 2048 * 16, bytes_f = (double)B * 2048 * 17;
     printf("B=%d tiles=%d in_rows=%d out_rows=%d\n", B, ntiles, in_rows, out_rows);
-    for (int var : {0, 2}) { const int spin = 0;
+    {
+        uint8_t *y;
+        const size_t nb = (size_t)ntiles * in_rows * 512;
+        CHECK(hipMalloc(&y, nb));
+        for (int blocks : {2048, 8192, 32768}) {
+            for (int r = 0; r < 2; r++) hipLaunchKernelGGL(copy_k, dim3(blocks), dim3(256), 0, 0, (const f4v *)x, (f4v *)y, nb / 16);
+            CHECK(hipDeviceSynchronize());
+            CHECK(hipEventRecord(e0));
+            for (int r = 0; r < 5; r++) hipLaunchKernelGGL(copy_k, dim3(blocks), dim3(256), 0, 0, (const f4v *)x, (f4v *)y, nb / 16);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
+            printf("float4 copy of %.2f GB, %5d blocks: %7.3f ms  %6.2f TB/s (read + write)\n", nb / 1e9, blocks, ms, 2.0 * nb / ms / 1e9);
+        }
+        CHECK(hipFree(y));
+    }
+    for (int var : {0}) { const int spin = 0;
         for (int mode : {1, 6, 7}) {
             for (int r = 0; r < 2; r++) {
                 hipLaunchKernelGGL(k, dim3(ntiles), dim3(128), lds, 0, x, o[0], o[1], o[2], o[3], o[4], o[5], o[6],
