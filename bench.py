@@ -82,11 +82,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # rehearsal on a one-GPU box: DSP_BENCH_BACKEND=gloo DSP_BENCH_DEVICE=0 runs every rank on GPU 0
+    backend = os.environ.get("DSP_BENCH_BACKEND", "nccl")
+    if "DSP_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["DSP_BENCH_DEVICE"])
     if world > 1:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     import dsp_amd
     from dsp_amd.pipeline import BurstPipeline, shard_range
@@ -149,7 +156,7 @@ def main():
     wall = time.perf_counter() - t0
     if dist is not None:
         import torch
-        tw = torch.tensor([wall, ev_ms], dtype=torch.float64, device="cuda")
+        tw = torch.tensor([wall, ev_ms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall, ev_ms = float(tw[0]), float(tw[1])
 
