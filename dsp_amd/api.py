@@ -413,3 +413,33 @@ def apply_fractional_shift(signal, shift, half_len=4, *, ctx=None):
     """hw1/test_lagrange_resampling.py:75-79."""
     positions = np.arange(len(signal), dtype=float) + shift
     return lagrange_resample(signal, positions, half_len, ctx=ctx)
+
+
+class FrequencyLockedLoop:
+    """API-shaped facade for the reference's ``fll.FrequencyLockedLoop`` (constructed at
+    fll_real_signal.py:66-71, f_rel.py:123-129; ``process_signal`` at :74 / :132; ``history`` keys
+    at fll_real_signal.py:107-125).  **Parity unpinned**: the class' source is absent from the
+    reference; the loop is this library's definition (include/dsp_hip.h dsp_fll_class)."""
+
+    _DET = {"cross_product": 0, "atan2": 1, "decision_directed": 2}
+
+    def __init__(self, detector_method="decision_directed", Kp=0.001, Ki=0.00005, freq_limit=0.05, *, ctx=None):
+        if detector_method not in self._DET:
+            raise ValueError(f"unknown detector_method {detector_method!r}")
+        self.detector_method, self.Kp, self.Ki, self.freq_limit = detector_method, Kp, Ki, freq_limit
+        self.history = {"errors": [], "freq_estimates": [], "phases": []}
+        self._ctx = ctx
+
+    def process_signal(self, signal):
+        ctx = self._ctx or default_context()
+        x, dt, rdt = _as_bursts(np.asarray(signal).reshape(1, -1))
+        N = x.shape[1]
+        out = np.zeros((1, max(N, 1)), x.dtype)
+        e = np.zeros((1, max(N, 1)), rdt); f = np.zeros_like(e); p = np.zeros_like(e)
+        fe = np.zeros(1)
+        if N:
+            check(_lib.lib().dsp_fll_class(ctx.handle, _vp(x), dt, 1, N, N, None, self._DET[self.detector_method],
+                                           float(self.Kp), float(self.Ki), float(self.freq_limit),
+                                           _vp(out), _vp(e), _vp(f), _vp(p), max(N, 1), _vp(fe)))
+        self.history = {"errors": e[0, :N].copy(), "freq_estimates": f[0, :N].copy(), "phases": p[0, :N].copy()}
+        return out[0, :N].copy(), float(fe[0])

@@ -767,6 +767,58 @@ int dsp_rx_chain(dsp_ctx *c, const void *x, int in_kind, int64_t B, int64_t N, i
                         ef, dec, n_out, out_stride);
 }
 
+// class FrequencyLockedLoop facade (nco_kernels.hip; parity unpinned: fll.py is absent)
+int dsp_fll_class(dsp_ctx *c, const void *x, int dtype, int64_t B, int64_t N, int64_t x_stride,
+                  const int32_t *lens, int detector, double Kp, double Ki, double freq_limit,
+                  void *out, void *errors, void *freqs, void *phases, int64_t out_stride, double *freq_estimate)
+{
+    if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    if (B < 0 || N < 0) return fail(DSP_E_ARG, "negative B or N");
+    if (B == 0 || N == 0) return DSP_OK;
+    if (!x) return fail(DSP_E_ARG, "x is NULL");
+    if (dtype != DSP_C64 && dtype != DSP_C128) return fail(DSP_E_ARG, "bad dtype");
+    if (detector < 0 || detector > 2) return fail(DSP_E_ARG, "detector must be 0 cross_product, 1 atan2, 2 decision_directed");
+    if (x_stride < N || out_stride < N) return fail(DSP_E_ARG, "stride < N");
+    if (!(freq_limit > 0.0)) return fail(DSP_E_ARG, "freq_limit must be > 0");
+    if (lens)
+        for (int64_t b = 0; b < B; b++)
+            if (lens[b] < 0 || lens[b] > N) return fail(DSP_E_ARG, "lens[%lld] out of range", (long long)b);
+    HIP_TRY(hipSetDevice(c->device));
+    const int ce = dtype == DSP_C128 ? 16 : 8, re = ce / 2;
+    const int64_t rows = dsp_tile_rows(N), ntiles = (B + 63) / 64;
+    hipStream_t s = c->stream;
+    DevBuf d_x, d_xt, d_lens, d_ff, d_stage;
+    HIP_TRY(d_x.alloc((size_t)B * x_stride * ce));
+    HIP_TRY(d_xt.alloc((size_t)ntiles * rows * 64 * ce));
+    HIP_TRY(hipMemcpyAsync(d_x.p, x, (size_t)B * x_stride * ce, hipMemcpyHostToDevice, s));
+    if (lens) {
+        HIP_TRY(d_lens.alloc((size_t)B * 4));
+        HIP_TRY(hipMemcpyAsync(d_lens.p, lens, (size_t)B * 4, hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(launch_tile_from_bursts(d_x.p, x_stride, d_lens.as<int>(), (int)N, (int)B, d_xt.p, (int)rows, ce, s));
+    struct OutSpec { void *host; int elem; DevBuf tiles; };
+    OutSpec outs[4] = {{out, ce, {}}, {errors, re, {}}, {freqs, re, {}}, {phases, re, {}}};
+    for (auto &o : outs)
+        if (o.host) {
+            HIP_TRY(o.tiles.alloc((size_t)ntiles * rows * 64 * o.elem));
+            HIP_TRY(hipMemsetAsync(o.tiles.p, 0, (size_t)ntiles * rows * 64 * o.elem, s));
+        }
+    HIP_TRY(d_ff.alloc((size_t)B * 8));
+    HIP_TRY(launch_fll_class(d_xt.p, dtype == DSP_C128, d_lens.as<int>(), (int)N, (int)B, (int)rows, detector, Kp, Ki,
+                             freq_limit, outs[0].tiles.p, outs[1].tiles.p, outs[2].tiles.p, outs[3].tiles.p,
+                             d_ff.as<double>(), s));
+    HIP_TRY(d_stage.alloc((size_t)B * out_stride * ce));
+    for (auto &o : outs) {
+        if (!o.host) continue;
+        HIP_TRY(launch_bursts_from_tiles(o.tiles.p, (int)rows, (int)B, d_stage.p, out_stride, (int)N, o.elem, s));
+        HIP_TRY(hipMemcpyAsync(o.host, d_stage.p, (size_t)B * out_stride * o.elem, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    if (freq_estimate) HIP_TRY(hipMemcpyAsync(freq_estimate, d_ff.p, (size_t)B * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return DSP_OK;
+}
+
 // lagrange_resample -- hw1/test_lagrange_resampling.py:34-72
 int dsp_lagrange_resample(dsp_ctx *c, const void *x, int dtype, int64_t n, const double *positions, int64_t P,
                           int half_len, double *out_c128)

@@ -134,3 +134,6 @@ hipError_t launch_seg_gather(const SegParams &P, uint8_t *dec_out, float *mu_out
 hipError_t launch_lagrange_resample(const void *x, int c128, int len, const double *pos, int64_t P, int half_len,
                                     void *out, hipStream_t s);
 hipError_t launch_stream_copy(const void *src, void *dst, size_t bytes, hipStream_t s);
+hipError_t launch_fll_class(const void *x, int c128, const int *lens, int len_all, int B, int rows, int detector,
+                            double Kp, double Ki, double flim, void *out, void *errs, void *freqs, void *phases,
+                            double *freq_final, hipStream_t s);

@@ -193,6 +193,17 @@ int64_t dsp_fir_workspace_bytes(int in_kind, int64_t B, int64_t N, int n_taps);
  * Returns DSP_E_ARG if the filter is too long for the LDS-tiled kernel (n_taps > ~80). */
 int dsp_fir_tiles_dev(dsp_ctx *ctx, const dsp_fir_args *args);
 
+/* Facade for the reference's class FrequencyLockedLoop(detector_method, Kp, Ki, freq_limit)
+ * .process_signal(x) (used by fll_real_signal.py:66-74,209-216, f_rel.py:123-132).  PARITY
+ * UNPINNED: fll.py itself is absent from the reference, so the loop is this library's own
+ * definition (accumulating-phase NCO, detector 0 cross_product / 1 atan2 / 2 decision_directed,
+ * PI filter with anti-windup, frequency clamp; dsp_amd/csrc/nco_kernels.hip).  B bursts [B][x_stride]
+ * of dtype; outputs [B][out_stride]: corrected samples (dtype), history errors / freq_estimates /
+ * phases (real of the same precision), any may be NULL; freq_estimate [B] float64.        */
+int dsp_fll_class(dsp_ctx *ctx, const void *x, int dtype, int64_t B, int64_t N, int64_t x_stride,
+                  const int32_t *lens, int detector, double Kp, double Ki, double freq_limit,
+                  void *out, void *errors, void *freqs, void *phases, int64_t out_stride, double *freq_estimate);
+
 /* lagrange_resample(signal, positions, half_len=4) -- hw1/test_lagrange_resampling.py:34-72
  * ((2h+1)-point barycentric Lagrange, neighbour indices clipped to [0, n-1] :58-59, exact-node
  * shortcut :62-66).  x: n samples of dtype DSP_C64 / DSP_C128 (a real signal is passed with zero

@@ -297,3 +297,32 @@ def sync_capture_segmented(x, sps=4, alpha=0.007, mu0=0.0, Bn=0.003, y=1.0, seg_
         p_last, j1_prev = pl, j1
     dec = np.concatenate(dec) if dec else np.zeros(0, np.uint8)
     return dict(n=dec.size, dec=dec, mu=np.concatenate(mu), freq=np.concatenate(freq), seg_info=info)
+
+
+def fll_class(x, detector="decision_directed", Kp=0.001, Ki=0.00005, freq_limit=0.05):
+    """CPU restatement of the library's OWN definition of the class-FLL facade
+    (dsp_amd/csrc/nco_kernels.hip).  Parity unpinned: the reference's fll.py is absent."""
+    x = np.asarray(x, np.complex128)
+    n = x.size
+    y = np.zeros(n, complex); err = np.zeros(n); fr = np.zeros(n); ph = np.zeros(n)
+    phase = freq = integ = 0.0
+    prev = 0j
+    for i in range(n):
+        yi = x[i] * np.exp(-1j * phase)
+        if detector == "decision_directed":
+            d = np.sign(yi.real) + 1j * np.sign(yi.imag)
+            e = float(np.angle(yi * np.conj(d)))
+        else:
+            z = yi * np.conj(prev)
+            e = float(np.angle(z)) if detector == "atan2" else float(z.imag / (abs(yi) * abs(prev) + 1e-12))
+        integ = min(max(integ + Ki * e, -freq_limit), freq_limit)
+        freq = min(max(Kp * e + integ, -freq_limit), freq_limit)
+        phase = phase + 2 * np.pi * freq
+        if phase > np.pi:
+            phase -= 2 * np.pi
+        elif phase <= -np.pi:
+            phase += 2 * np.pi
+        prev = yi
+        y[i] = yi; err[i] = e; fr[i] = freq; ph[i] = phase
+    t0 = n - (n + 3) // 4
+    return y, (float(np.mean(fr[t0:])) if n else 0.0), err, fr, ph
