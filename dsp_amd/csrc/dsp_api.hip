@@ -884,7 +884,7 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
     HIP_TRY(hipMemsetAsync(d_tiles.p, 0, (size_t)ntiles * rows * 64 * 8, st));
 
     // ---- windows -> tiles (optionally through the matched filter) ------------------------
-    DevBuf d_peak, d_c64, d_ws, d_inv, d_starts0, d_lens0, d_part;
+    DevBuf d_peak, d_c64, d_ws, d_inv, d_lo, d_hi, d_part;
     const float *in_scale = nullptr;
     if (a->in_kind == DSP_I16) {
         HIP_TRY(d_peak.alloc(16));
@@ -893,32 +893,29 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
                               a->h ? nullptr : d_c64.p, st));
         in_scale = d_peak.as<float>() + 1;
     }
-    HIP_TRY(launch_seg_windows(S, n, seg, lead, tail, d_starts.as<int64_t>(), d_lens.as<int>(), st));
+    HIP_TRY(d_lo.alloc((size_t)S * 4)); HIP_TRY(d_hi.alloc((size_t)S * 4));
+    HIP_TRY(launch_seg_windows(S, n, seg, lead, tail, d_starts.as<int64_t>(), d_lens.as<int>(), d_lo.as<int>(),
+                               d_hi.as<int>(), st));
+    const double *d_scale = nullptr;
     if (a->h) {
-        // pass 1: statistics of the whole filtered stream over the non-overlapping partition
-        HIP_TRY(d_starts0.alloc((size_t)S * 8)); HIP_TRY(d_lens0.alloc((size_t)S * 4));
-        HIP_TRY(launch_seg_windows(S, n, seg, 0, 0, d_starts0.as<int64_t>(), d_lens0.as<int>(), st));
-        FirParams P;
-        memset(&P, 0, sizeof(P));
-        if (!fir_plan(a->in_kind, a->n_taps, (int)seg, P))
-            return fail(DSP_E_ARG, "capture: %d taps are too many for the LDS-tiled filter", a->n_taps);
-        HIP_TRY(d_ws.alloc((size_t)S * P.nchunk * 32));
-        HIP_TRY(d_inv.alloc((size_t)S * 8));
-        P.src = a->x; P.starts = d_starts0.as<int64_t>(); P.n_total = n; P.lens = d_lens0.as<int>();
-        P.len_all = (int)seg; P.B = S; P.h = a->h; P.M = a->n_taps; P.start = (a->n_taps - 1) / 2;
-        P.in_scale = in_scale; P.dst = nullptr; P.rows = (int)rows; P.stats = d_ws.as<double>();
-        HIP_TRY(launch_fir_tile(P, a->in_kind, st));
-        HIP_TRY(d_part.alloc((size_t)1024 * 32));
-        HIP_TRY(launch_fir_stats_global(P.stats, (int64_t)S * P.nchunk, S, nullptr, d_inv.as<double>(),
-                                        d_part.as<double>(), 1024, st));
-        // pass 2: the overlapping windows, scaled by 1/std, one rounding into complex64
+        // ONE filter pass over the overlapping windows: unscaled fl32(y) into the tiles, statistics
+        // over each window's own samples only (the windows' shares partition the stream), merged
+        // into the np.std of the whole filtered stream; 1/std is applied by the recurrence kernel
         FirParams Q;
         memset(&Q, 0, sizeof(Q));
-        if (!fir_plan(a->in_kind, a->n_taps, (int)Nw, Q)) return fail(DSP_E_ARG, "capture: filter plan failed");
+        if (!fir_plan(a->in_kind, a->n_taps, (int)Nw, Q))
+            return fail(DSP_E_ARG, "capture: %d taps are too many for the LDS-tiled filter", a->n_taps);
+        HIP_TRY(d_ws.alloc((size_t)S * Q.nchunk * 32));
+        HIP_TRY(d_inv.alloc((size_t)S * 8));
+        HIP_TRY(d_part.alloc((size_t)1024 * 32));
         Q.src = a->x; Q.starts = d_starts.as<int64_t>(); Q.n_total = n; Q.lens = d_lens.as<int>();
+        Q.stat_lo = d_lo.as<int>(); Q.stat_hi = d_hi.as<int>();
         Q.len_all = (int)Nw; Q.B = S; Q.h = a->h; Q.M = a->n_taps; Q.start = (a->n_taps - 1) / 2;
-        Q.in_scale = in_scale; Q.dst = d_tiles.p; Q.rows = (int)rows; Q.scale = d_inv.as<double>();
+        Q.in_scale = in_scale; Q.dst = d_tiles.p; Q.rows = (int)rows; Q.stats = d_ws.as<double>();
         HIP_TRY(launch_fir_tile(Q, a->in_kind, st));
+        HIP_TRY(launch_fir_stats_global(Q.stats, (int64_t)S * Q.nchunk, S, nullptr, d_inv.as<double>(),
+                                        d_part.as<double>(), 1024, st));
+        d_scale = d_inv.as<double>();
     } else {
         const void *src = a->in_kind == DSP_I16 ? d_c64.p : a->x;
         HIP_TRY(launch_tile_from_bursts(src, 0, d_lens.as<int>(), (int)Nw, S, d_tiles.p, (int)rows, 8, st,
@@ -929,7 +926,7 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
     dsp_sync_args sa;
     memset(&sa, 0, sizeof(sa));
     sa.x = d_tiles.p; sa.dtype = DSP_C64; sa.variant = DSP_GARDNER2; sa.B = S; sa.N = Nw; sa.in_rows = rows;
-    sa.lens = d_lens.as<int32_t>(); sa.sps = sps; sa.alpha = a->alpha; sa.mu0 = a->mu0; sa.do_fll = 1;
+    sa.lens = d_lens.as<int32_t>(); sa.scale = d_scale; sa.sps = sps; sa.alpha = a->alpha; sa.mu0 = a->mu0; sa.do_fll = 1;
     sa.Bn = a->Bn; sa.y = a->y; sa.mu = a->mu ? d_mu.p : nullptr; sa.pos = d_pos.p; sa.dec = d_dec.as<uint8_t>(); sa.freq = a->freq ? d_freq.p : nullptr;
     sa.out_rows = out_rows; sa.n_out = d_nout.as<int32_t>(); sa.status = d_status.as<int32_t>();
     {

@@ -77,6 +77,7 @@ struct FirParams {
     // neighbours across window edges and zeros only beyond the stream's own ends)
     const int64_t *starts;    // [B] or NULL -> src + b * ld, zeros outside [0, len)
     int64_t n_total;
+    const int *stat_lo, *stat_hi;   // [B] window-local range that counts in the statistics, or NULL -> [0, len)
     const double *h;          // device taps [M]
     int M, start;             // y[n] = sum_j h[j] x[n + start - j]
     const float *in_scale;    // device scalar applied to int16 samples in float32, or NULL
@@ -127,7 +128,7 @@ struct SegParams {
     int64_t *off;             // [S + 1] output offset of each window's first kept symbol
 };
 hipError_t launch_seg_windows(int S, int64_t n_total, int64_t seg_len, int64_t lead, int64_t tail,
-                              int64_t *starts, int *lens, hipStream_t s);
+                              int64_t *starts, int *lens, int *own_lo, int *own_hi, hipStream_t s);
 hipError_t launch_seg_stitch(const SegParams &P, int overlap_vote, hipStream_t s);
 hipError_t launch_seg_gather(const SegParams &P, uint8_t *dec_out, float *mu_out, float *freq_out,
                              int64_t capacity, hipStream_t s);

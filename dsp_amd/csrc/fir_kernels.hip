@@ -98,6 +98,8 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
     const int b = tile * 64 + lane;
     const int len = b < P.B ? (P.lens ? P.lens[b] : P.len_all) : 0;
     const double scale = (P.scale && b < P.B) ? P.scale[b] : 1.0;
+    const int st_lo = (P.stat_lo && b < P.B) ? P.stat_lo[b] : 0;
+    const int st_hi = (P.stat_hi && b < P.B) ? P.stat_hi[b] : len;
     const ST *xrow = xs + (size_t)lane * stride;
     OUT *dst = P.dst ? (OUT *)P.dst + (size_t)tile * P.rows * 64 + lane : nullptr;
     const int per_wave = CH / 4;
@@ -130,9 +132,10 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
             for (int o = 0; o < OG; o++) {
                 const int n = n0 + o0 + o;
                 const bool valid = n < len;
-                yre[g * OG + o] = valid ? are[o] : 0.0;
-                yim[g * OG + o] = valid ? aim[o] : 0.0;
-                if (valid) { s_re += are[o]; s_im += aim[o]; cnt++; }
+                const bool counts = valid && n >= st_lo && n < st_hi;
+                yre[g * OG + o] = counts ? are[o] : 0.0;
+                yim[g * OG + o] = counts ? aim[o] : 0.0;
+                if (counts) { s_re += are[o]; s_im += aim[o]; cnt++; }
                 if (dst && n < P.rows) put(dst + (size_t)n * 64, valid ? are[o] * scale : 0.0,
                                            valid ? aim[o] * scale : 0.0);
             }
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
     for (int j = 0; j < 32; j++) {
         if (j < per_wave) {
             const int n = n0 + w * per_wave + j;
-            if (n < len) {
+            if (n < len && n >= st_lo && n < st_hi) {
                 const double dr = yre[j] - m_re, di = yim[j] - m_im;
                 m2 += dr * dr + di * di;
             }

@@ -36,7 +36,8 @@ __device__ __forceinline__ unsigned rot_quadrant(unsigned q, int r)
 }
 
 __global__ void seg_windows_k(int S, int64_t n_total, int64_t seg_len, int64_t lead, int64_t tail,
-                              int64_t *__restrict__ starts, int *__restrict__ lens)
+                              int64_t *__restrict__ starts, int *__restrict__ lens,
+                              int *__restrict__ own_lo, int *__restrict__ own_hi)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
@@ -46,6 +47,11 @@ __global__ void seg_windows_k(int S, int64_t n_total, int64_t seg_len, int64_t l
     if (en > n_total || s == S - 1) en = n_total;
     starts[s] = st;
     lens[s] = (int)(en - st);
+    // the segment's own samples inside its window (the partition the stream statistics run over)
+    int64_t o_hi = (int64_t)(s + 1) * seg_len;
+    if (o_hi > n_total) o_hi = n_total;
+    if (own_lo) own_lo[s] = (int)((int64_t)s * seg_len - st);
+    if (own_hi) own_hi[s] = (int)(o_hi - st);
 }
 
 // rows of a tiled float array of window s
@@ -222,10 +228,10 @@ hipError_t launch_lagrange_resample(const void *x, int c128, int len, const doub
 }
 
 hipError_t launch_seg_windows(int S, int64_t n_total, int64_t seg_len, int64_t lead, int64_t tail,
-                              int64_t *starts, int *lens, hipStream_t s)
+                              int64_t *starts, int *lens, int *own_lo, int *own_hi, hipStream_t s)
 {
     hipLaunchKernelGGL(seg_windows_k, dim3((S + 255) / 256), dim3(256), 0, s, S, n_total, seg_len, lead, tail,
-                       starts, lens);
+                       starts, lens, own_lo, own_hi);
     return hipGetLastError();
 }
 

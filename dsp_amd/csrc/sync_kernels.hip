@@ -324,7 +324,7 @@ __device__ __forceinline__ dspm::GOut timing_iter(const Tile<IN> &tl, dspm::GSta
 // no per-lane commit selects.  Returns false (state untouched) when a lane fails the vote.
 template <typename IN, bool SC>
 __device__ __forceinline__ bool g2_steady(const Tile<IN> &tl, dspm::GState &gs, const TimingConst &tc,
-                                          cd &rec, double &err)
+                                          cd &rec, double &err, double &pos)
 {
     const double mu = gs.mu, spsd = tc.spsd;
     const double kd = (double)gs.k;
@@ -352,6 +352,7 @@ __device__ __forceinline__ bool g2_steady(const Tile<IN> &tl, dspm::GState &gs, 
         rec = dspm::g2_interp(i_o, tc.len, (const dspm::LagrangeW *)nullptr, FetchFn<IN>{tl});
     }
     err = e;
+    pos = i_o;
     gs.mu = mu_n;
     gs.k += tc.sps;                                      // :98
     return true;
@@ -617,11 +618,12 @@ __global__ __launch_bounds__(128) void sync_split_kernel(SyncParams P)
         int min_len = len;
         for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(min_len, d); min_len = o < min_len ? o : min_len; }
         min_len = __builtin_amdgcn_readfirstlane(min_len);
-        const bool steady_ok = VARIANT == DSP_VARIANT_GARDNER2 && ring && o_rec && o_terr && o_mu && !o_pos;
+        const bool steady_ok = VARIANT == DSP_VARIANT_GARDNER2 && ring;
         bool all_active = __all(gs.active);
         const unsigned char *rec_t = (const unsigned char *)(o_rec + (size_t)tile * out_rows * 64);
         const unsigned char *err_t = (const unsigned char *)(o_terr + (size_t)tile * out_rows * 64);
         const unsigned char *mu_t = (const unsigned char *)(o_mu + (size_t)tile * out_rows * 64);
+        const unsigned char *pos_t = (const unsigned char *)(o_pos + (size_t)tile * out_rows * 64);
         const unsigned lane_s = lane * (unsigned)sizeof(OS), lane_c = lane * (unsigned)sizeof(OC);
         int n_steady = 0;
         // DMA blocks (T iterations) and queue blocks (TQ iterations) tick independently
@@ -638,16 +640,17 @@ __global__ __launch_bounds__(128) void sync_split_kernel(SyncParams P)
                 DSP_TR(trp, 0);
                 bool done = false;
                 if (steady) {
-                    cd rec; double e;
-                    done = g2_steady<IN, SC>(tl, gs, tc, rec, e);
+                    cd rec; double e, ps;
+                    done = g2_steady<IN, SC>(tl, gs, tc, rec, e, ps);
                     if (done) {
                         DSP_TR(trp, 5);
                         const unsigned row_s = (unsigned)it * 64u * (unsigned)sizeof(OS);
                         const unsigned row_c = (unsigned)(it + ROFF) * 64u * (unsigned)sizeof(OC);
                         OC rv = {(OS)rec.re, (OS)rec.im};
-                        sst(rec_t, lane_c + row_c, rv);
-                        sst(err_t, lane_s + row_s, (OS)e);
-                        sst(mu_t, lane_s + row_s, (OS)gs.mu);
+                        if (o_rec) sst(rec_t, lane_c + row_c, rv);
+                        if (o_terr) sst(err_t, lane_s + row_s, (OS)e);
+                        if (o_mu) sst(mu_t, lane_s + row_s, (OS)gs.mu);
+                        if (o_pos) sst(pos_t, lane_s + row_s, (OS)ps);
                         DSP_TR(trp, 6);
                         d2v qv = {rec.re, rec.im};
                         q_data[(buf * TQ + tq) * 64 + lane] = qv;

@@ -224,7 +224,8 @@ int dsp_lagrange_resample(dsp_ctx *ctx, const void *x, int dtype, int64_t n, con
  *   x        DSP_I16 interleaved int16 I,Q (peak-normalised like read_iq_int16 when normalize)
  *            or DSP_C64 complex64 samples
  *   h        matched-filter taps: np.convolve(x, h, 'same') / np.std over the WHOLE capture
- *            (worker.py:173-178), or NULL = x is already filtered
+ *            (worker.py:173-178), or NULL = x is already filtered.  The filter output is held as
+ *            complex64 and 1/std is applied by the recurrence kernel (like dsp_rx_chain)
  *   outputs  one entry per symbol of the stitched stream (capacity entries available):
  *            dec quadrant index, mu (float32, may be NULL), freq (float32, may be NULL);
  *            *n_symbols receives the count; seg_info (may be NULL) [S][4] int32:

@@ -249,8 +249,9 @@ def _positions(start, mu, n, sps):
 
 
 def sync_capture_segmented(x, sps=4, alpha=0.007, mu0=0.0, Bn=0.003, y=1.0, seg_len=65536, warmup=2048,
-                           vote=None):
-    """x: the whole capture, complex64, already matched-filtered and normalised."""
+                           vote=None, scale=1.0):
+    """x: the whole capture, complex64, already matched-filtered; scale: factor applied to the
+    samples in float64 (1/std of the whole filtered stream when the device filters)."""
     x = np.ascontiguousarray(x, dtype=np.complex64)
     n = x.size
     S = (n + seg_len - 1) // seg_len
@@ -260,7 +261,7 @@ def sync_capture_segmented(x, sps=4, alpha=0.007, mu0=0.0, Bn=0.003, y=1.0, seg_
     for s in range(S):
         st = max(0, s * seg_len - lead)
         en = n if s == S - 1 else min(n, (s + 1) * seg_len + tail)
-        o = sync_chain_c64(x[st:en], sps=sps, alpha=alpha, mu0=mu0, Bn=Bn, y=y)
+        o = sync_chain_c64(x[st:en], sps=sps, alpha=alpha, mu0=mu0, Bn=Bn, y=y, scale=scale)
         pos = _positions(float(st), o["mu"], o["n"], sps)
         wins.append((o, pos))
     dec, mu, freq, info = [], [], [], np.zeros((S, 4), np.int32)

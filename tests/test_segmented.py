@@ -96,8 +96,9 @@ def test_gpu_segmented_int16_with_matched_filter(oracle, stream, ctx):
     w[1::2] = np.round(x.imag / pk * 20000)
     got = dsp_amd.sync_capture_segmented(w, SPS, 0.007, 0.0, 0.003, 1, taps=h, seg_len=16384, warmup=1024, ctx=ctx)
     xc = oracle.read_iq_int16_words(w, True)
-    yc = oracle.filter_samples(xc, h).astype(np.complex64)
-    ref = oracle.sync_capture_segmented(yc, SPS, 0.007, 0.0, 0.003, 1.0, seg_len=16384, warmup=1024)
+    yf = oracle.convolve_same(xc, h)                      # unscaled, held as complex64 on the device
+    ref = oracle.sync_capture_segmented(yf.astype(np.complex64), SPS, 0.007, 0.0, 0.003, 1.0, seg_len=16384,
+                                        warmup=1024, scale=1.0 / oracle.np_std(yf))
     assert got["n"] == ref["n"]
     # the device filter accumulates in another order: last-ulp differences of the complex64 input
     assert np.mean(got["dec"] == ref["dec"]) > 0.9999

@@ -71,7 +71,7 @@ def main():
             "segments": pipe.S, "symbols": nsym, "ms": ms, "wall_ms": wall * 1e3,
             "Msamples_per_s": n / ms / 1e3, "symbol_match_rate": rate,
             "lean_bytes_per_sample": 4.25, "lean_GBps": n * 4.25 / ms / 1e6,
-            "stages": "peak + 2x RRC(int16->c64 tiles, whole-stream std) + Gardner/FLL over windows + stitch"}
+            "stages": "peak + RRC (int16 -> complex64 window tiles + whole-stream std) + Gardner/FLL over windows + stitch"}
     print(json.dumps(line), flush=True)
     pipe.close()
     ctx.close()
