@@ -129,3 +129,28 @@ def test_gpu_capture_pipeline_device_generated(ctx):
         info = pipe.info
         assert (info[1:, 0] > 4000).all() and (info[:, 1] > info[:, 0]).all()
         pipe.close()
+
+
+@pytest.mark.gpu
+def test_gpu_segmented_edge_shapes(oracle, stream, ctx):
+    """Ragged ends: capture shorter than one segment, a last segment of a few symbols, no warm-up,
+    a capture length that is not a multiple of sps, and bad arguments."""
+    import dsp_amd
+    q, x, h, y = stream
+    cases = [(y[:5000], 8192, 256),          # one segment: the plain sequential chain
+             (y[:16384 + 40], 16384, 512),   # second segment of 10 symbols
+             (y[:50001], 4096, 0),           # odd length, no warm-up (shares still tile the stream)
+             (y[:30000], 4096, 2048)]        # warm-up longer than the segment
+    for xs, seg_len, warm in cases:
+        ref = oracle.sync_capture_segmented(xs, SPS, 0.007, 0.0, 0.003, 1.0, seg_len=seg_len, warmup=warm)
+        got = dsp_amd.sync_capture_segmented(xs, SPS, 0.007, 0.0, 0.003, 1, seg_len=seg_len, warmup=warm, ctx=ctx)
+        assert got["n"] == ref["n"], (len(xs), seg_len, warm)
+        assert np.array_equal(got["seg_info"], ref["seg_info"])
+        assert np.array_equal(got["dec"], ref["dec"])
+    o = oracle.sync_chain_c64(y[:5000], sps=SPS, alpha=0.007, Bn=0.003)
+    got = dsp_amd.sync_capture_segmented(y[:5000], SPS, 0.007, 0.0, 0.003, 1, seg_len=8192, warmup=256, ctx=ctx)
+    assert got["n"] == o["n"] and np.array_equal(got["dec"], o["dec"])
+    with pytest.raises(dsp_amd.DspError):
+        dsp_amd.sync_capture_segmented(y[:5000], SPS, seg_len=4098, ctx=ctx)      # not a multiple of sps
+    with pytest.raises(IndexError):
+        dsp_amd.sync_capture_segmented(np.zeros(0, np.complex64), SPS, ctx=ctx)
