@@ -13,7 +13,8 @@ from .api import (rrc_filter, fll_gains, interpolate_sample, gardner_timing_reco
                   gardner_ted, fll_func, gardner_batch, fll_batch, sync_chain_batch,
                   read_iq_int16, read_iq_int16_words, read_iq_float32, fir_batch, filter_samples,
                   rx_chain_batch, sync_capture_segmented, lagrange_resample,
-                  apply_fractional_shift, FrequencyLockedLoop)
+                  apply_fractional_shift, FrequencyLockedLoop, diff_corr, find_preamble_offset,
+                  find_optimal_sampling_phase)
 
 __all__ = [
     "Context", "DspError", "default_context", "build", "lib",
@@ -21,5 +22,5 @@ __all__ = [
     "gardner_timing_recovery", "gardner_ted", "fll_func",
     "gardner_batch", "fll_batch", "sync_chain_batch",
     "read_iq_int16", "read_iq_int16_words", "read_iq_float32", "fir_batch", "filter_samples",
-    "rx_chain_batch", "sync_capture_segmented", "lagrange_resample", "apply_fractional_shift", "FrequencyLockedLoop",
+    "rx_chain_batch", "sync_capture_segmented", "lagrange_resample", "apply_fractional_shift", "FrequencyLockedLoop", "diff_corr", "find_preamble_offset", "find_optimal_sampling_phase",
 ]

@@ -443,3 +443,57 @@ class FrequencyLockedLoop:
                                            _vp(out), _vp(e), _vp(f), _vp(p), max(N, 1), _vp(fe)))
         self.history = {"errors": e[0, :N].copy(), "freq_estimates": f[0, :N].copy(), "phases": p[0, :N].copy()}
         return out[0, :N].copy(), float(fe[0])
+
+
+def diff_corr(signal_iq, preamble_iq, sps, *, ctx=None):
+    """The sliding normalised differential correlation of find_preamble_offset
+    (diff_method.py:118-148): a list of sps complex64 arrays, conv_results[phase] of length
+    len(signal_iq[phase::sps]) - 1."""
+    ctx = ctx or default_context()
+    x = np.asarray(signal_iq)
+    if x.dtype == np.complex64:
+        x, dt = np.ascontiguousarray(x), DSP_C64
+    else:
+        x, dt = np.ascontiguousarray(x, dtype=np.complex128), DSP_C128
+    pre = np.ascontiguousarray(preamble_iq, dtype=np.complex128)
+    if pre.size < 2:
+        raise ValueError("the preamble needs at least two symbols")
+    sps = int(sps)
+    lens = [max(len(range(p, x.size, sps)) - 1, 0) for p in range(sps)]
+    ks = max(max(lens), 1)
+    conv = np.zeros((sps, ks), np.complex64)
+    if x.size:
+        check(_lib.lib().dsp_diff_corr(ctx.handle, _vp(x), dt, x.size, _vp(pre), pre.size, sps, _vp(conv), ks))
+    return [conv[p, :lens[p]].copy() for p in range(sps)]
+
+
+def find_preamble_offset(signal_iq, preamble_iq, sps, *, ctx=None):
+    """diff_method.find_preamble_offset (diff_method.py:92-162):
+    returns (offset, signal_aligned, conv_results, conv_max, phase_offset)."""
+    signal_iq = np.asarray(signal_iq)
+    conv_results = diff_corr(signal_iq, preamble_iq, sps, ctx=ctx)
+    conv_max = [(np.argmax(np.abs(c)), np.max(np.abs(c))) for c in conv_results]          # :150
+    values = [val for idx, val in conv_max]                                                # :153
+    offset_index = int(np.argmax(values))
+    offset = conv_max[offset_index][0]
+    phase_offset = offset_index
+    signal_aligned = signal_iq[offset * sps + phase_offset:]                               # :158
+    return offset, signal_aligned, conv_results, conv_max, phase_offset
+
+
+def find_optimal_sampling_phase(signal_filtered, preamble_symbols, sps, preamble_length=None):
+    """diff_method.find_optimal_sampling_phase (diff_method.py:41-89): sps correlations of
+    len(preamble) symbols each -- a few hundred multiplies, kept in numpy on the host."""
+    if preamble_length is None:
+        preamble_length = len(preamble_symbols)
+    else:
+        preamble_length = min(preamble_length, len(preamble_symbols))
+    preamble_ref = preamble_symbols[:preamble_length]
+    correlations = np.zeros(sps)
+    for phase in range(sps):
+        sampled = signal_filtered[phase::sps]
+        if len(sampled) < preamble_length:
+            correlations[phase] = 0
+            continue
+        correlations[phase] = np.abs(np.sum(sampled[:preamble_length] * np.conj(preamble_ref)))
+    return np.argmax(correlations), correlations

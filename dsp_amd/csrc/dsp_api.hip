@@ -767,6 +767,37 @@ int dsp_rx_chain(dsp_ctx *c, const void *x, int in_kind, int64_t B, int64_t N, i
                         ef, dec, n_out, out_stride);
 }
 
+// differential-correlation preamble search -- diff_method.py:92-162 (preamble_kernels.hip)
+int dsp_diff_corr(dsp_ctx *c, const void *x, int dtype, int64_t n, const double *preamble_c128, int n_pre, int sps,
+                  float *conv_c64, int64_t k_stride)
+{
+    if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    if (dtype != DSP_C64 && dtype != DSP_C128) return fail(DSP_E_ARG, "diff_corr: dtype must be DSP_C64 or DSP_C128");
+    if (!x || !preamble_c128 || !conv_c64) return fail(DSP_E_ARG, "diff_corr: NULL argument");
+    if (n < 1 || sps < 1 || sps > 64) return fail(DSP_E_ARG, "diff_corr: bad n / sps");
+    if (n_pre < 2 || n_pre > 4096) return fail(DSP_E_ARG, "diff_corr: the preamble needs 2..4096 symbols");
+    if (k_stride < 1) return fail(DSP_E_ARG, "diff_corr: k_stride < 1");
+    const int L = n_pre - 1;
+    std::vector<double> dpre((size_t)L * 2);
+    for (int j = 0; j < L; j++) {                    // d_pre = pre[1:] * conj(pre[:-1])   :118
+        const double ar = preamble_c128[2 * j], ai = preamble_c128[2 * j + 1];
+        const double br = preamble_c128[2 * j + 2], bi = preamble_c128[2 * j + 3];
+        dpre[2 * j] = br * ar + bi * ai;
+        dpre[2 * j + 1] = bi * ar - br * ai;
+    }
+    const size_t eb = dtype == DSP_C128 ? 16 : 8;
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf d_x, d_p, d_c;
+    HIP_TRY(d_x.alloc((size_t)n * eb)); HIP_TRY(d_p.alloc((size_t)L * 16));
+    HIP_TRY(d_c.alloc((size_t)sps * k_stride * 8));
+    HIP_TRY(hipMemcpyAsync(d_x.p, x, (size_t)n * eb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_p.p, dpre.data(), (size_t)L * 16, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_diff_corr(d_x.p, dtype == DSP_C128, n, sps, d_p.p, L, d_c.p, k_stride, c->stream));
+    HIP_TRY(hipMemcpyAsync(conv_c64, d_c.p, (size_t)sps * k_stride * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DSP_OK;
+}
+
 // class FrequencyLockedLoop facade (nco_kernels.hip; parity unpinned: fll.py is absent)
 int dsp_fll_class(dsp_ctx *c, const void *x, int dtype, int64_t B, int64_t N, int64_t x_stride,
                   const int32_t *lens, int detector, double Kp, double Ki, double freq_limit,

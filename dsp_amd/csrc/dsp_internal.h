@@ -138,3 +138,5 @@ hipError_t launch_stream_copy(const void *src, void *dst, size_t bytes, hipStrea
 hipError_t launch_fll_class(const void *x, int c128, const int *lens, int len_all, int B, int rows, int detector,
                             double Kp, double Ki, double flim, void *out, void *errs, void *freqs, void *phases,
                             double *freq_final, hipStream_t s);
+hipError_t launch_diff_corr(const void *x, int c128, int64_t n, int sps, const void *dpre, int L, void *conv,
+                            int64_t kstride, hipStream_t s);

@@ -193,6 +193,16 @@ int64_t dsp_fir_workspace_bytes(int in_kind, int64_t B, int64_t N, int n_taps);
  * Returns DSP_E_ARG if the filter is too long for the LDS-tiled kernel (n_taps > ~80). */
 int dsp_fir_tiles_dev(dsp_ctx *ctx, const dsp_fir_args *args);
 
+/* Differential-correlation preamble search -- the sliding loop of
+ * find_preamble_offset, diff_method.py:118-148 (= worker.py:183-245): for phase in 0..sps-1,
+ * s = x[phase::sps], d = s[1:]*conj(s[:-1]), conv[phase][k] = sum(d[k:k+L]*conj(d_pre)) /
+ * np.std(d[k:k+L]) (0 where the window's std is 0), L = n_pre - 1, complex64 like :137.
+ * x: n samples of dtype (host); preamble: n_pre complex128 symbols; conv: [sps][k_stride]
+ * complex64, zero beyond the last full window of each phase (k_stride >= len(x[phase::sps]) - 1
+ * holds every phase).  The arg-max / peak picking of :151-160 stays with the caller.        */
+int dsp_diff_corr(dsp_ctx *ctx, const void *x, int dtype, int64_t n, const double *preamble_c128, int n_pre,
+                  int sps, float *conv_c64, int64_t k_stride);
+
 /* Facade for the reference's class FrequencyLockedLoop(detector_method, Kp, Ki, freq_limit)
  * .process_signal(x) (used by fll_real_signal.py:66-74,209-216, f_rel.py:123-132).  PARITY
  * UNPINNED: fll.py itself is absent from the reference, so the loop is this library's own

@@ -327,3 +327,26 @@ def fll_class(x, detector="decision_directed", Kp=0.001, Ki=0.00005, freq_limit=
         y[i] = yi; err[i] = e; fr[i] = freq; ph[i] = phase
     t0 = n - (n + 3) // 4
     return y, (float(np.mean(fr[t0:])) if n else 0.0), err, fr, ph
+
+
+def find_preamble_offset(signal_iq, preamble_iq, sps):
+    """diff_method.py:92-162 restated loop for loop (numpy; the per-window np.std and np.sum are
+    the reference's own calls).  Returns (offset, signal_aligned, conv_results, conv_max, phase)."""
+    signal_iq = np.asarray(signal_iq)
+    preamble_iq = np.asarray(preamble_iq)
+    d_pre = preamble_iq[1:] * np.conj(preamble_iq[:-1])                 # :118
+    conv_results, conv_max = [], []
+    for phase in range(sps):
+        s = signal_iq[phase::sps]                                      # :124
+        d = s[1:] * np.conj(s[:-1])                                    # :125
+        conv = np.zeros(len(d), dtype=np.complex64)                    # :137
+        for k in range(len(d) - len(d_pre) + 1):                       # :140
+            cur = d[k:k + len(d_pre)]
+            Y = np.std(cur)
+            conv[k] = np.sum(cur * np.conj(d_pre)) / Y if Y > 0 else 0   # :143-148
+        conv_results.append(conv)
+        conv_max.append((np.argmax(np.abs(conv)), np.max(np.abs(conv))))   # :151
+    values = [v for _, v in conv_max]
+    idx = int(np.argmax(values))
+    offset = conv_max[idx][0]
+    return offset, signal_iq[offset * sps + idx:], conv_results, conv_max, idx

@@ -1,0 +1,102 @@
+"""Differential-correlation preamble search: find_preamble_offset,
+diff_method.py:92-162.  The golden vectors come from the reference itself
+(tests/golden/make_golden_preamble.py): config 2's capture (burst at symbol 518, phase 1) and a
+synthetic complex64 case with a dead stretch (windows whose std is 0)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden, GOLDEN
+
+
+def test_oracle_find_preamble_offset(oracle):
+    g = golden("g_diffcorr")
+    off, aligned, conv, cmax, ph = oracle.find_preamble_offset(g["sig"], g["pre"], 4)
+    assert (off, ph) == (518, 1) == (int(g["offset"]), int(g["phase"]))
+    assert len(aligned) == int(g["n_aligned"])
+    for p in range(4):
+        assert np.array_equal(conv[p], g[f"conv{p}"])
+    off, aligned, conv, cmax, ph = oracle.find_preamble_offset(g["syn_x"], g["syn_pre"], 2)
+    assert (off, ph) == (int(g["syn_offset"]), int(g["syn_phase"]))
+    assert np.array_equal(conv[0], g["syn_conv0"]) and np.array_equal(conv[1], g["syn_conv1"])
+
+
+@pytest.mark.gpu
+def test_gpu_find_preamble_offset_config2(ctx):
+    import dsp_amd
+    g = golden("g_diffcorr")
+    off, aligned, conv, cmax, ph = dsp_amd.find_preamble_offset(g["sig"], g["pre"], 4, ctx=ctx)
+    assert (off, ph) == (518, 1)
+    assert len(aligned) == int(g["n_aligned"]) and np.array_equal(aligned, g["sig"][518 * 4 + 1:])
+    for p in range(4):
+        ref = g[f"conv{p}"]
+        assert conv[p].shape == ref.shape and conv[p].dtype == np.complex64
+        assert np.max(np.abs(conv[p] - ref)) <= 2e-6 * np.max(np.abs(ref))     # float64 sums, complex64 store
+        assert int(cmax[p][0]) == int(g["conv_max"][p, 0])
+        assert abs(cmax[p][1] - g["conv_max"][p, 1]) < 1e-5 * g["conv_max"][p, 1]
+    bp, corr = dsp_amd.find_optimal_sampling_phase(aligned, g["pre"], 4)
+    assert int(bp) == int(g["best_phase"]) and np.allclose(corr, g["phase_corr"], rtol=1e-12)
+
+
+@pytest.mark.gpu
+def test_gpu_find_preamble_offset_full_capture(ctx):
+    """diff_method.py:164-190 on the whole 43 956-sample capture."""
+    import dsp_amd
+    from scipy.signal import firwin, lfilter
+    g = golden("g_diffcorr")
+    raw = np.fromfile(os.path.join(GOLDEN, "data", "sig_symb_x4_ncr_77671952566_logon_id_1_tx_id_7616.pcm"),
+                      dtype=np.float32)
+    sig = raw[::2] + 1j * raw[1::2]
+    sig = sig * np.exp(-1j * 2 * np.pi * 0.0105 * np.arange(len(sig)))
+    sig = lfilter(firwin(101, cutoff=0.14, window="hamming", fs=1.0), 1.0, sig)
+    sig = sig / np.std(sig)
+    assert len(sig) == int(g["n_full"])
+    off, aligned, conv, cmax, ph = dsp_amd.find_preamble_offset(sig, g["pre"], 4, ctx=ctx)
+    assert (off, ph) == (int(g["offset_full"]), int(g["phase_full"])) == (518, 1)
+    for p in range(4):
+        assert int(cmax[p][0]) == int(g["conv_max_full"][p, 0])
+        assert abs(cmax[p][1] - g["conv_max_full"][p, 1]) < 1e-5 * g["conv_max_full"][p, 1]
+    assert len(aligned) == 41883
+
+
+@pytest.mark.gpu
+def test_gpu_find_preamble_offset_complex64_and_dead_windows(oracle, ctx):
+    import dsp_amd
+    g = golden("g_diffcorr")
+    x, pre = g["syn_x"], g["syn_pre"]
+    assert x.dtype == np.complex64
+    off, aligned, conv, cmax, ph = dsp_amd.find_preamble_offset(x, pre, 2, ctx=ctx)
+    assert (off, ph) == (int(g["syn_offset"]), int(g["syn_phase"])) == (100, 0)
+    for p in range(2):
+        ref = g[f"syn_conv{p}"]                       # the reference ran this one in float32 (complex64 in)
+        assert conv[p].shape == ref.shape
+        assert np.max(np.abs(conv[p] - ref)) <= 1e-4 * np.max(np.abs(ref))
+        assert np.array_equal(conv[p] == 0, ref == 0)          # dead windows and the tail stay 0
+    # float64 definition on the upcast samples = the reference on x.astype(complex128)
+    o2 = oracle.find_preamble_offset(x.astype(np.complex128), pre, 2)
+    for p in range(2):
+        assert np.max(np.abs(conv[p] - o2[2][p])) <= 2e-6 * np.max(np.abs(o2[2][p]))
+    with pytest.raises(ValueError):
+        dsp_amd.diff_corr(x, pre[:1], 2, ctx=ctx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("interp", [False, True])
+def test_gpu_worker_processing(ctx, interp):
+    """worker.Processing.process (worker.py:276-337) end to end on the seeded worker.Generation signal
+    the reference itself processed: same peaks, same number of bursts, same derotated symbols."""
+    from dsp_amd.receiver import Processing
+    g = golden("g_worker")
+    tag = "i" if interp else "n"
+    pr = Processing(signal=g["w_samples"], preamble=g["w_pre"], packet_symb=g["w_symbols"], sps=4,
+                    constellation="qpsk", interp=interp, ctx=ctx)
+    peaks, found = pr.process()
+    assert np.array_equal(np.asarray(peaks), g[f"w_peaks_{tag}"])
+    assert len(found) == int(g[f"w_nfound_{tag}"])
+    for j, s in enumerate(found):
+        ref = g[f"w_found_{tag}{j}"]
+        assert s.shape == ref.shape
+        assert np.max(np.abs(s - ref)) < 1e-9
+        quad = lambda z: (z.real < 0).astype(np.uint8) + 2 * (z.imag < 0)      # noqa: E731
+        assert np.array_equal(quad(s), quad(ref))
