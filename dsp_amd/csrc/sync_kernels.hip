@@ -1,23 +1,27 @@
 // sync_kernels.hip -- the receiver synchronisation recurrences on gfx950.
 //
-// One wavefront (one 64-thread workgroup) owns one tile of 64 bursts, one
-// burst per lane, and walks the Gardner timing loop (gardner2.py:63-98 or
-// hw1/gardner.py:45-72) and the decision-directed FLL (fll_func.py:14-26)
-// symbol by symbol with all loop state in VGPRs (float64).
+// One workgroup owns one tile of 64 bursts, one burst per lane, and walks the Gardner timing
+// loop (gardner2.py:63-98 or hw1/gardner.py:45-72) and the decision-directed FLL
+// (fll_func.py:14-26) symbol by symbol with all loop state in VGPRs (float64).
+//   sync_split_kernel  two waves per tile: wave 0 = timing loop, wave 1 = FLL + slicer, coupled
+//                      by a double-buffered LDS queue (the default when both loops run);
+//   sync_kernel        one wave does everything (single loops, Lagrange interpolator, FLL only).
 //
 // Memory system design (CDNA4):
-//   * the tile's input is ONE contiguous stream of 64-lane rows; the wave
-//     streams it into a private LDS ring with LDS-DMA (global_load_lds_dwordx4,
-//     1 KiB per instruction, no VGPR staging) several symbols ahead of use;
-//   * each lane then picks the rows its own fractional delay needs out of the
-//     ring with ds_read (bank-conflict free: lane l always reads column l);
-//   * outputs leave as full-row stores (64 lanes x 4/8/16 B contiguous).
-//   The DMA and the stores are issued through inline asm so that their count
-//   in the in-order vmcnt queue is exact: once per block of T symbols the wave
-//   waits with s_waitcnt vmcnt(N), N = the stores issued since the previous
-//   block's DMA, which retires that DMA while leaving the stores in flight.
-//   Lanes whose rows fall outside the ring window (symbol slips, tails) read
-//   global memory directly; that path is rare and keeps every input correct.
+//   * the tile's input is ONE contiguous stream of 64-lane rows; the timing wave streams it
+//     into a private LDS ring with LDS-DMA (global_load_lds_dwordx4, 1 KiB per instruction,
+//     up to four pieces per M0 setup, no VGPR staging) a block of symbols ahead of use;
+//   * each lane then picks the rows its own fractional delay needs out of the ring with
+//     ds_read (bank-conflict free: lane l always reads column l);
+//   * outputs leave as full-row stores (64 lanes x 1/4/8/16 B contiguous).
+//   The DMA and the stores are issued through inline asm so that their count in the in-order
+//   vmcnt queue is exact: once per block the wave waits with s_waitcnt vmcnt(N), N = the
+//   stores issued since the previous block's DMA, which retires that DMA while leaving the
+//   stores in flight.
+// Control flow per symbol (wave-uniform votes pick the path, every input stays correct):
+//   steady   all lanes active, window clear of the burst ends: one vote, no commit selects;
+//   fast     the same arithmetic committed per lane by select;
+//   generic  per-lane code: mu wrap loops (symbol slips), rows outside the ring from global memory.
 #include "dsp_internal.h"
 #include "sync_lane.h"
 
