@@ -34,7 +34,7 @@ __device__ __forceinline__ d2v to_stage(d2v v, float) { return v; }
 __device__ __forceinline__ void put(f2v *p, double re, double im) { *p = f2v{(float)re, (float)im}; }
 __device__ __forceinline__ void put(d2v *p, double re, double im) { *p = d2v{re, im}; }
 
-template <typename IN, typename OUT, int OG>
+template <typename IN, typename OUT, int OG, int KS>
 __global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
 {
     typedef typename Stage<IN>::T ST;
@@ -52,12 +52,12 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
 
     for (int i = threadIdx.x; i < m8; i += 256) hrev[i] = i < M ? P.h[M - 1 - i] : 0.0;
     // stage the input windows: xs[bb][i] = x[b][n0 + start - (M-1) + i], zero outside the burst.
-    // W < 128 (fir_plan), so a wave covers a row in two steps; all 32 loads of a wave are issued
-    // before the first LDS write (each wave would otherwise pay the HBM latency 32 times in a row).
+    // W <= 64 * KS (launch_fir_tile_t), so a wave covers a row in KS steps; all 16 * KS loads of a wave are
+    // issued before the first LDS write (each wave would otherwise pay the HBM latency once per load).
     const int x0 = n0 + P.start - (M - 1);
     {
-        IN v[16][2];
-        bool ok[16][2];
+        IN v[16][KS];
+        bool ok[16][KS];
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int b = tile * 64 + w * 16 + q;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
                 const int64_t st = live ? P.starts[b] : 0;
                 const IN *src = (const IN *)P.src;
 #pragma unroll
-                for (int k = 0; k < 2; k++) {
+                for (int k = 0; k < KS; k++) {
                     const int i = lane + 64 * k;
                     const int64_t g = st + x0 + i;
                     ok[q][k] = live && i < W && g >= 0 && g < P.n_total;
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
                 const int len = live ? (P.lens ? P.lens[b] : P.len_all) : 0;
                 const IN *src = (const IN *)P.src + (int64_t)(live ? b : 0) * P.ld;
 #pragma unroll
-                for (int k = 0; k < 2; k++) {
+                for (int k = 0; k < KS; k++) {
                     const int i = lane + 64 * k, n = x0 + i;
                     ok[q][k] = i < W && n >= 0 && n < len;
                     v[q][k] = src[ok[q][k] ? n : 0];
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
 #pragma unroll
         for (int q = 0; q < 16; q++) {
 #pragma unroll
-            for (int k = 0; k < 2; k++) {
+            for (int k = 0; k < KS; k++) {
                 const int i = lane + 64 * k;
                 if (i < W) xs[(size_t)(w * 16 + q) * stride + i] = ok[q][k] ? to_stage(v[q][k], isc) : ST{0, 0};
             }
@@ -380,7 +380,16 @@ hipError_t launch_fir_tile_t(const FirParams &P, hipStream_t s)
     size_t xs_bytes = (size_t)64 * P.stride * sizeof(typename Stage<IN>::T);
     if (xs_bytes < (size_t)4 * 64 * 4 * 8) xs_bytes = (size_t)4 * 64 * 4 * 8;
     size_t lds = (size_t)((P.M + 7) & ~7) * 8 + xs_bytes;
-    hipLaunchKernelGGL((fir_tile_kernel<IN, OUT, OG>), dim3(nchunk, ntiles), dim3(256), lds, s, P);
+    if (P.W > 192) return hipErrorInvalidValue;
+    if (P.W > 128) {
+        // more than 64 KB of dynamic LDS has to be asked for (per device: cheap, so every launch)
+        hipError_t e = hipFuncSetAttribute((const void *)fir_tile_kernel<IN, OUT, OG, 3>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((fir_tile_kernel<IN, OUT, OG, 3>), dim3(nchunk, ntiles), dim3(256), lds, s, P);
+    } else {
+        hipLaunchKernelGGL((fir_tile_kernel<IN, OUT, OG, 2>), dim3(nchunk, ntiles), dim3(256), lds, s, P);
+    }
     return hipGetLastError();
 }
 
@@ -393,13 +402,13 @@ bool fir_plan(int in_kind, int M, int n_out, FirParams &P)
     const int og = in_kind == DSP_IN_C128 ? 4 : 8;
     if (M > 4096) return false;
     const int m8 = (M + 7) & ~7;
-    const size_t budget = 64 * 1024 - (size_t)m8 * 8;
+    const size_t budget = 80 * 1024 - (size_t)m8 * 8;   // two workgroups per CU (160 KB of LDS)
     int best = 0;
     // CH / 4 outputs per wave, a whole number of og-output register blocks
     for (int CH = 128; CH >= 4 * og; CH -= 4 * og) {
         int W = CH + m8 - 1;               // highest staged index read: CH + ceil8(M) - 2
         int stride = W | 1;
-        if ((size_t)64 * stride * elem <= budget) { best = CH; break; }
+        if (W <= 192 && (size_t)64 * stride * elem <= budget) { best = CH; break; }
     }
     if (!best) return false;
     P.CH = best; P.W = best + m8 - 1; P.stride = P.W | 1;
