@@ -14,7 +14,8 @@ from .api import (rrc_filter, fll_gains, interpolate_sample, gardner_timing_reco
                   read_iq_int16, read_iq_int16_words, read_iq_float32, fir_batch, filter_samples,
                   rx_chain_batch, sync_capture_segmented, lagrange_resample,
                   apply_fractional_shift, FrequencyLockedLoop, diff_corr, find_preamble_offset,
-                  find_optimal_sampling_phase)
+                  find_optimal_sampling_phase, preamble_cfo, estimate_initial_frequency,
+                  estimate_initial_frequency_batch, derotate, rx_bursts)
 
 __all__ = [
     "Context", "DspError", "default_context", "build", "lib",
@@ -23,4 +24,5 @@ __all__ = [
     "gardner_batch", "fll_batch", "sync_chain_batch",
     "read_iq_int16", "read_iq_int16_words", "read_iq_float32", "fir_batch", "filter_samples",
     "rx_chain_batch", "sync_capture_segmented", "lagrange_resample", "apply_fractional_shift", "FrequencyLockedLoop", "diff_corr", "find_preamble_offset", "find_optimal_sampling_phase",
+    "preamble_cfo", "estimate_initial_frequency", "estimate_initial_frequency_batch", "derotate", "rx_bursts",
 ]

@@ -137,6 +137,12 @@ def _declare(L):
     L.dsp_synth_bursts_dev.argtypes = [vp, C.c_uint64, i64, i64, ci, ci, vp, ci, dbl, vp]
     L.dsp_synth_stream_dev.argtypes = [vp, C.c_uint64, i64, ci, vp, ci, dbl, dbl, dbl, dbl, ci, dbl, vp]
     L.dsp_diff_corr.argtypes = [vp, vp, ci, i64, vp, ci, ci, vp, i64]
+    L.dsp_cfo_preamble.argtypes = [vp, vp, ci, i64, vp, i64, ci, vp, ci, vp]
+    L.dsp_cfo_fourth_power.argtypes = [vp, vp, ci, i64, i64, i64, vp, i64, vp]
+    L.dsp_derotate.argtypes = [vp, vp, ci, i64, vp, i64, i64, vp, vp, vp, i64]
+    L.dsp_cfo_derotate_dev.argtypes = [vp, vp, ci, i64, vp, i64, i64, ci, vp, ci, ci, vp, vp]
+    L.dsp_rx_bursts.argtypes = [vp, vp, ci, i64, vp, i64, i64, vp, ci, ci, vp, vp, ci, ci, ci, dbl, dbl, ci, ci,
+                                dbl, dbl, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp]
     L.dsp_fll_class.argtypes = [vp, vp, ci, i64, i64, i64, vp, ci, dbl, dbl, dbl, vp, vp, vp, vp, i64, vp]
     L.dsp_lagrange_resample.argtypes = [vp, vp, ci, i64, vp, i64, ci, vp]
     L.dsp_sync_capture_segmented.argtypes = [vp, C.POINTER(CaptureArgs)]
@@ -149,7 +155,8 @@ def _declare(L):
                  "dsp_gardner", "dsp_fll", "dsp_sync_chain", "dsp_tile_bursts_dev",
                  "dsp_untile_dev", "dsp_sync_tiles_dev", "dsp_load_iq_i16", "dsp_load_iq_f32",
                  "dsp_fir_same_std", "dsp_rx_chain", "dsp_fir_tiles_dev", "dsp_synth_bursts_dev",
-                 "dsp_sync_capture_segmented", "dsp_sync_capture_segmented_dev", "dsp_synth_stream_dev", "dsp_lagrange_resample", "dsp_fll_class", "dsp_diff_corr"):
+                 "dsp_sync_capture_segmented", "dsp_sync_capture_segmented_dev", "dsp_synth_stream_dev", "dsp_lagrange_resample", "dsp_fll_class", "dsp_diff_corr",
+                 "dsp_cfo_preamble", "dsp_cfo_fourth_power", "dsp_derotate", "dsp_rx_bursts", "dsp_cfo_derotate_dev"):
         getattr(L, name).restype = ci
 
 

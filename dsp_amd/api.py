@@ -497,3 +497,114 @@ def find_optimal_sampling_phase(signal_filtered, preamble_symbols, sps, preamble
             continue
         correlations[phase] = np.abs(np.sum(sampled[:preamble_length] * np.conj(preamble_ref)))
     return np.argmax(correlations), correlations
+
+
+# ---------------------------------------------------------------------------
+# coarse frequency estimators and the pre-derotation
+def _as_signal(x):
+    x = np.asarray(x)
+    if x.dtype == np.complex64:
+        return np.ascontiguousarray(x), DSP_C64
+    return np.ascontiguousarray(x, dtype=np.complex128), DSP_C128
+
+
+def preamble_cfo(signal_iq, preamble_iq, sps, offsets=None, *, ctx=None):
+    """The preamble-aided coarse frequency estimates of diff_method.py:267-292 (method 1 is also
+    worker.py:288-294): with s = signal_iq[offset::sps][:len(preamble)], p = s * conj(preamble) and
+    phases = np.unwrap(np.angle(p)), returns f_rel by (1) mean phase step, (2) least-squares slope,
+    (3) angle of the mean lag-1 product, each / (2 pi sps): float64[3], or [B, 3] for a sequence of
+    sample offsets into one signal (one burst each)."""
+    ctx = ctx or default_context()
+    x, dt = _as_signal(signal_iq)
+    pre = np.ascontiguousarray(preamble_iq, dtype=np.complex128)
+    if pre.size < 2:
+        raise ValueError("the preamble needs at least two symbols")
+    single = offsets is None
+    off = np.zeros(1, np.int64) if single else np.ascontiguousarray(offsets, dtype=np.int64).ravel()
+    out = np.zeros((off.size, 3), np.float64)
+    check(_lib.lib().dsp_cfo_preamble(ctx.handle, _vp(x), dt, x.size, _vp(off), off.size, int(sps), _vp(pre),
+                                     pre.size, _vp(out)))
+    return out[0] if single else out
+
+
+def estimate_initial_frequency_batch(signals, num_samples, lens=None, *, ctx=None):
+    """estimate_initial_frequency for every row of a [B, N] block in one call -> float64[B]."""
+    ctx = ctx or default_context()
+    x = np.asarray(signals)
+    x = np.ascontiguousarray(x) if x.dtype == np.complex64 else np.ascontiguousarray(x, dtype=np.complex128)
+    if x.ndim != 2:
+        raise ValueError("signals must be [B, N]")
+    B, N = x.shape
+    out = np.zeros(B, np.float64)
+    check(_lib.lib().dsp_cfo_fourth_power(ctx.handle, _vp(x), DSP_C64 if x.dtype == np.complex64 else DSP_C128,
+                                         B, N, N, _vp(_lens(lens, B, N)),
+                                         int(num_samples), _vp(out)))
+    return out
+
+
+def estimate_initial_frequency(signal, num_samples, *, ctx=None):
+    """estimate_freq.estimate_initial_frequency (estimate_freq.py:4-58): fourth-power lag-1
+    estimate over the first num_samples symbols, cycles per symbol; 0.0 for fewer than two."""
+    x = np.asarray(signal).reshape(1, -1)
+    if x.shape[1] == 0:
+        return 0.0
+    return float(estimate_initial_frequency_batch(x, num_samples, ctx=ctx)[0])
+
+
+def derotate(signal, f_rel, offset=0, *, ctx=None):
+    """signal * np.exp(-1j * 2 * np.pi * f_rel * (np.arange(len(signal)) + offset))
+    (diff_method.py:296-298, worker.py:298) -> complex128."""
+    ctx = ctx or default_context()
+    x, dt = _as_signal(signal)
+    out = np.zeros(x.size, np.complex128)
+    if x.size:
+        f = np.array([f_rel], np.float64)
+        i0 = np.array([offset], np.int64)
+        check(_lib.lib().dsp_derotate(ctx.handle, _vp(x), dt, x.size, None, 1, x.size, _vp(f), _vp(i0), _vp(out),
+                                     x.size))
+    return out
+
+
+def rx_bursts(signal_iq, offsets, n_pkt, preamble_iq, taps, sps=4, alpha=0.007, mu_initial=0.0, Bn=0.03, y=1, *,
+              cfo_method=1, f_rel=None, variant=DSP_GARDNER2, normalize_std=True, interp_half_len=0,
+              outputs="all", capacity=None, ctx=None):
+    """The per-burst body of worker.Processing.process (worker.py:284-304) for every burst of one
+    signal in one device call: coarse CFO from the preamble (cfo_method 1..3, or f_rel given), cut
+    of n_pkt samples at each offset, derotation with the absolute sample index, RRC + /np.std,
+    Gardner, FLL.  Returns a dict of [B, cap] complex128 / float64 arrays + "n_out", "std", "f_rel"."""
+    ctx = ctx or default_context()
+    x, dt = _as_signal(signal_iq)
+    off = np.ascontiguousarray(offsets, dtype=np.int64).ravel()
+    B = off.size
+    pre = np.ascontiguousarray(preamble_iq, dtype=np.complex128) if preamble_iq is not None else None
+    h = np.ascontiguousarray(taps, dtype=np.float64)
+    fin = None
+    if f_rel is not None:
+        fin = np.ascontiguousarray(np.broadcast_to(np.asarray(f_rel, np.float64), (B,)))
+        cfo_method = 0
+    names = ("rec", "err", "mu", "sig", "freq", "ef", "dec") if outputs == "all" else tuple(outputs)
+    n_pkt, sps = int(n_pkt), int(sps)
+    cap = int(capacity) if capacity else n_pkt // sps + 8
+    L = _lib.lib()
+    for attempt in range(2):
+        bufs = {}
+        for nm in names:
+            dtp = np.complex128 if nm in ("rec", "sig") else (np.uint8 if nm == "dec" else np.float64)
+            bufs[nm] = np.zeros((B, cap), dtype=dtp)
+        n_out = np.zeros(B, dtype=np.int32)
+        std = np.zeros(B, dtype=np.float64)
+        fout = np.zeros(B, dtype=np.float64)
+        g = lambda nm: _vp(bufs.get(nm))  # noqa: E731
+        rc = L.dsp_rx_bursts(ctx.handle, _vp(x), dt, x.size, _vp(off), B, n_pkt, _vp(pre),
+                             pre.size if pre is not None else 0, int(cfo_method), _vp(fin), _vp(h), h.size,
+                             int(bool(normalize_std)), sps, float(alpha), float(mu_initial), int(variant),
+                             int(interp_half_len), float(Bn), float(y),
+                             g("rec"), g("err"), g("mu"), g("sig"), g("freq"), g("ef"), g("dec"),
+                             _vp(n_out), cap, _vp(fout), _vp(std))
+        if rc == _lib.DSP_E_CAPACITY and attempt == 0 and capacity is None:
+            cap *= 4
+            continue
+        check(rc)
+        break
+    bufs.update(n_out=n_out, std=std, f_rel=fout)
+    return bufs

@@ -592,14 +592,18 @@ struct FirStage {
 
 static int fir_stage(dsp_ctx *c, FirStage &S, const void *x, int in_kind, int64_t B, int64_t N,
                      int64_t x_stride, const int32_t *lens, int normalize_peak, const double *h,
-                     int n_taps, int start, bool want_std, bool scaled_output)
+                     int n_taps, int start, bool want_std, bool scaled_output, bool x_on_device = false)
 {
     const int ie = in_elem_bytes(in_kind), oe = in_kind == DSP_C128 ? 16 : 8;
     hipStream_t s = c->stream;
     S.rows = dsp_tile_rows(N);
     const int64_t ntiles = (B + 63) / 64;
-    HIP_TRY(S.d_x.alloc((size_t)B * x_stride * ie));
-    HIP_TRY(hipMemcpyAsync(S.d_x.p, x, (size_t)B * x_stride * ie, hipMemcpyHostToDevice, s));
+    void *d_src = const_cast<void *>(x);              // bursts already resident (burst cutter) ...
+    if (!x_on_device) {                               // ... or uploaded here
+        HIP_TRY(S.d_x.alloc((size_t)B * x_stride * ie));
+        HIP_TRY(hipMemcpyAsync(S.d_x.p, x, (size_t)B * x_stride * ie, hipMemcpyHostToDevice, s));
+        d_src = S.d_x.p;
+    }
     if (lens) {
         HIP_TRY(S.d_lens.alloc((size_t)B * 4));
         HIP_TRY(hipMemcpyAsync(S.d_lens.p, lens, (size_t)B * 4, hipMemcpyHostToDevice, s));
@@ -614,7 +618,7 @@ static int fir_stage(dsp_ctx *c, FirStage &S, const void *x, int in_kind, int64_
     const float *in_scale = nullptr;
     if (in_kind == DSP_I16) {
         // one peak over the whole [B][x_stride] block (a capture cut into bursts shares its peak)
-        HIP_TRY(launch_iq_i16(S.d_x.p, B * x_stride, normalize_peak, S.d_peak.as<unsigned>(),
+        HIP_TRY(launch_iq_i16(d_src, B * x_stride, normalize_peak, S.d_peak.as<unsigned>(),
                               S.d_peak.as<float>() + 1, nullptr, s));
         in_scale = S.d_peak.as<float>() + 1;
     }
@@ -627,7 +631,7 @@ static int fir_stage(dsp_ctx *c, FirStage &S, const void *x, int in_kind, int64_
         HIP_TRY(hipMemsetAsync(d_y64.p, 0, (size_t)B * N * 16, s));
         FirParams P;
         memset(&P, 0, sizeof(P));
-        P.src = S.d_x.p; P.ld = x_stride; P.lens = S.d_lens.as<int>(); P.len_all = (int)N; P.B = (int)B;
+        P.src = d_src; P.ld = x_stride; P.lens = S.d_lens.as<int>(); P.len_all = (int)N; P.B = (int)B;
         P.h = S.d_h.as<double>(); P.M = n_taps; P.start = start < 0 ? (n_taps - 1) / 2 : start;
         P.in_scale = in_scale;
         HIP_TRY(launch_fir_direct(P, in_kind, d_y64.p, N, (int)N, s));
@@ -651,7 +655,7 @@ static int fir_stage(dsp_ctx *c, FirStage &S, const void *x, int in_kind, int64_
     }
     dsp_fir_args a;
     memset(&a, 0, sizeof(a));
-    a.src = S.d_x.p; a.in_kind = in_kind; a.start = start; a.B = B; a.N = N; a.src_stride = x_stride;
+    a.src = d_src; a.in_kind = in_kind; a.start = start; a.B = B; a.N = N; a.src_stride = x_stride;
     a.lens = S.d_lens.as<int32_t>(); a.h = S.d_h.as<double>(); a.n_taps = n_taps; a.in_scale = in_scale;
     a.rows = S.rows;
     int64_t wsb = dsp_fir_workspace_bytes(in_kind, B, N, n_taps);
@@ -796,6 +800,204 @@ int dsp_diff_corr(dsp_ctx *c, const void *x, int dtype, int64_t n, const double 
     HIP_TRY(hipMemcpyAsync(conv_c64, d_c.p, (size_t)sps * k_stride * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DSP_OK;
+}
+
+// ---- coarse CFO estimators + burst cutter (cfo_kernels.hip) --------------------
+static int check_cuts(const char *who, int64_t n, const int64_t *offsets, int64_t B, int64_t span)
+{
+    for (int64_t b = 0; b < B; b++)
+        if (offsets[b] < 0 || offsets[b] + span > n)
+            return fail(DSP_E_ARG, "%s: burst %lld (offset %lld, %lld samples) leaves the signal of %lld samples", who,
+                        (long long)b, (long long)offsets[b], (long long)span, (long long)n);
+    return DSP_OK;
+}
+
+int dsp_cfo_preamble(dsp_ctx *c, const void *x, int dtype, int64_t n, const int64_t *offsets, int64_t B, int sps,
+                     const double *preamble_c128, int n_pre, double *f_rel)
+{
+    if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    if (dtype != DSP_C64 && dtype != DSP_C128) return fail(DSP_E_ARG, "cfo_preamble: dtype must be DSP_C64 or DSP_C128");
+    if (B < 0) return fail(DSP_E_ARG, "cfo_preamble: negative B");
+    if (B == 0) return DSP_OK;
+    if (!x || !offsets || !preamble_c128 || !f_rel) return fail(DSP_E_ARG, "cfo_preamble: NULL argument");
+    if (sps < 1 || n < 1) return fail(DSP_E_ARG, "cfo_preamble: bad n / sps");
+    if (n_pre < 2 || n_pre > 4096) return fail(DSP_E_ARG, "cfo_preamble: the preamble needs 2..4096 symbols");
+    if (B > 0x7fffffff) return fail(DSP_E_ARG, "cfo_preamble: too many bursts");
+    int rc = check_cuts("cfo_preamble", n, offsets, B, (int64_t)(n_pre - 1) * sps + 1);
+    if (rc != DSP_OK) return rc;
+    const size_t eb = dtype == DSP_C128 ? 16 : 8;
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf d_x, d_o, d_p, d_f;
+    HIP_TRY(d_x.alloc((size_t)n * eb)); HIP_TRY(d_o.alloc((size_t)B * 8));
+    HIP_TRY(d_p.alloc((size_t)n_pre * 16)); HIP_TRY(d_f.alloc((size_t)B * 24));
+    HIP_TRY(hipMemcpyAsync(d_x.p, x, (size_t)n * eb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_o.p, offsets, (size_t)B * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_p.p, preamble_c128, (size_t)n_pre * 16, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_cfo_preamble(d_x.p, dtype == DSP_C128, d_o.as<int64_t>(), (int)B, sps, d_p.p, n_pre,
+                                d_f.as<double>(), c->stream));
+    HIP_TRY(hipMemcpyAsync(f_rel, d_f.p, (size_t)B * 24, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DSP_OK;
+}
+
+int dsp_cfo_fourth_power(dsp_ctx *c, const void *x, int dtype, int64_t B, int64_t N, int64_t x_stride,
+                         const int32_t *lens, int64_t num_samples, double *freq)
+{
+    if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    if (dtype != DSP_C64 && dtype != DSP_C128) return fail(DSP_E_ARG, "cfo_fourth_power: dtype must be DSP_C64 or DSP_C128");
+    if (B < 0 || N < 0 || N > 0x7fffffff || B > 0x7fffffff) return fail(DSP_E_ARG, "cfo_fourth_power: bad B or N");
+    if (B == 0) return DSP_OK;
+    if (!freq || (!x && N > 0)) return fail(DSP_E_ARG, "cfo_fourth_power: NULL argument");
+    if (x_stride < N) return fail(DSP_E_ARG, "cfo_fourth_power: x_stride < N");
+    if (lens)
+        for (int64_t b = 0; b < B; b++)
+            if (lens[b] < 0 || lens[b] > N) return fail(DSP_E_ARG, "lens[%lld] out of range", (long long)b);
+    if (N == 0) { for (int64_t b = 0; b < B; b++) freq[b] = 0.0; return DSP_OK; }
+    const size_t eb = dtype == DSP_C128 ? 16 : 8;
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf d_x, d_l, d_f;
+    HIP_TRY(d_x.alloc((size_t)B * x_stride * eb)); HIP_TRY(d_f.alloc((size_t)B * 8));
+    HIP_TRY(hipMemcpyAsync(d_x.p, x, (size_t)B * x_stride * eb, hipMemcpyHostToDevice, c->stream));
+    if (lens) {
+        HIP_TRY(d_l.alloc((size_t)B * 4));
+        HIP_TRY(hipMemcpyAsync(d_l.p, lens, (size_t)B * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(launch_cfo_fourth_power(d_x.p, dtype == DSP_C128, x_stride, d_l.as<int>(), (int)N, (int)B, num_samples,
+                                    d_f.as<double>(), c->stream));
+    HIP_TRY(hipMemcpyAsync(freq, d_f.p, (size_t)B * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DSP_OK;
+}
+
+int dsp_derotate(dsp_ctx *c, const void *x, int dtype, int64_t n, const int64_t *offsets, int64_t B, int64_t n_cut,
+                 const double *f_rel, const int64_t *index0, double *out_c128, int64_t out_stride)
+{
+    if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    if (dtype != DSP_C64 && dtype != DSP_C128) return fail(DSP_E_ARG, "derotate: dtype must be DSP_C64 or DSP_C128");
+    if (B < 0 || n_cut < 0) return fail(DSP_E_ARG, "derotate: negative B or n_cut");
+    if (B == 0 || n_cut == 0) return DSP_OK;
+    if (!x || !f_rel || !out_c128) return fail(DSP_E_ARG, "derotate: NULL argument");
+    if (out_stride < n_cut) return fail(DSP_E_ARG, "derotate: out_stride < n_cut");
+    if (B > 0x7fffffff) return fail(DSP_E_ARG, "derotate: too many bursts");
+    if (offsets) {
+        int rc = check_cuts("derotate", n, offsets, B, n_cut);
+        if (rc != DSP_OK) return rc;
+    } else if (n_cut > n) {
+        return fail(DSP_E_ARG, "derotate: n_cut > n");
+    }
+    const size_t eb = dtype == DSP_C128 ? 16 : 8;
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf d_x, d_o, d_i, d_f, d_y;
+    HIP_TRY(d_x.alloc((size_t)n * eb)); HIP_TRY(d_f.alloc((size_t)B * 8));
+    HIP_TRY(d_y.alloc((size_t)B * out_stride * 16));
+    HIP_TRY(hipMemcpyAsync(d_x.p, x, (size_t)n * eb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_f.p, f_rel, (size_t)B * 8, hipMemcpyHostToDevice, c->stream));
+    if (offsets) {
+        HIP_TRY(d_o.alloc((size_t)B * 8));
+        HIP_TRY(hipMemcpyAsync(d_o.p, offsets, (size_t)B * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    if (index0) {
+        HIP_TRY(d_i.alloc((size_t)B * 8));
+        HIP_TRY(hipMemcpyAsync(d_i.p, index0, (size_t)B * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    if (out_stride > n_cut) HIP_TRY(hipMemsetAsync(d_y.p, 0, (size_t)B * out_stride * 16, c->stream));
+    HIP_TRY(launch_derotate_cut(d_x.p, dtype == DSP_C128, d_o.as<int64_t>(), d_i.as<int64_t>(), d_f.as<double>(), 1,
+                                (int)B, n_cut, d_y.p, out_stride, c->stream));
+    HIP_TRY(hipMemcpyAsync(out_c128, d_y.p, (size_t)B * out_stride * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DSP_OK;
+}
+
+// device-resident core of dsp_rx_bursts' front end: estimate (cfo_method 1..3 -> d_f [B][3]) or take
+// (cfo_method 0, d_f [B]) the frequency, then cut + derotate into complex128 [B][n_pkt].  Asynchronous.
+int dsp_cfo_derotate_dev(dsp_ctx *c, const void *d_x, int dtype, int64_t n, const int64_t *d_offsets, int64_t B,
+                         int64_t n_pkt, int sps, const double *d_preamble_c128, int n_pre, int cfo_method,
+                         double *d_f, double *d_out_c128)
+{
+    if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    if (dtype != DSP_C64 && dtype != DSP_C128) return fail(DSP_E_ARG, "cfo_derotate: dtype must be DSP_C64 or DSP_C128");
+    if (!d_x || !d_offsets || !d_f || !d_out_c128) return fail(DSP_E_ARG, "cfo_derotate: NULL argument");
+    if (B < 1 || B > 0x7fffffff || n_pkt < 1 || n_pkt > n || sps < 1) return fail(DSP_E_ARG, "cfo_derotate: bad sizes");
+    if (cfo_method < 0 || cfo_method > 3) return fail(DSP_E_ARG, "cfo_derotate: cfo_method is 0 or 1..3");
+    if (cfo_method != 0 && (!d_preamble_c128 || n_pre < 2 || n_pre > 4096 || (int64_t)(n_pre - 1) * sps + 1 > n_pkt))
+        return fail(DSP_E_ARG, "cfo_derotate: the preamble needs 2..4096 symbols inside the packet");
+    HIP_TRY(hipSetDevice(c->device));
+    int f_stride = 1;
+    const double *d_fsel = d_f;
+    if (cfo_method != 0) {
+        HIP_TRY(launch_cfo_preamble(d_x, dtype == DSP_C128, d_offsets, (int)B, sps, d_preamble_c128, n_pre, d_f,
+                                    c->stream));
+        d_fsel = d_f + (cfo_method - 1);
+        f_stride = 3;
+    }
+    // phase index = arange + offset (worker.py:298)
+    HIP_TRY(launch_derotate_cut(d_x, dtype == DSP_C128, d_offsets, nullptr, d_fsel, f_stride, (int)B, n_pkt,
+                                d_out_c128, n_pkt, c->stream));
+    return DSP_OK;
+}
+
+// worker.Processing.process per-burst body (worker.py:284-304) for all bursts at once: the signal goes
+// to the device once; coarse CFO from the preamble, cut + derotation, matched filter + /std, Gardner,
+// FLL all stay there; only the requested outputs come back.
+int dsp_rx_bursts(dsp_ctx *c, const void *x, int dtype, int64_t n, const int64_t *offsets, int64_t B, int64_t n_pkt,
+                  const double *preamble_c128, int n_pre, int cfo_method, const double *f_rel_in,
+                  const double *h, int n_taps, int normalize_std, int sps, double alpha, double mu0, int variant,
+                  int interp_half_len, double Bn, double y,
+                  void *rec, void *err, void *mu, void *sig, void *freq, void *ef, uint8_t *dec,
+                  int32_t *n_out, int64_t out_stride, double *f_rel_out, double *std_out)
+{
+    if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    if (dtype != DSP_C64 && dtype != DSP_C128) return fail(DSP_E_ARG, "rx_bursts: dtype must be DSP_C64 or DSP_C128");
+    if (B < 0 || n_pkt < 0) return fail(DSP_E_ARG, "rx_bursts: negative B or n_pkt");
+    if (B == 0) return DSP_OK;
+    if (!x || !offsets || !h || n_taps < 1) return fail(DSP_E_ARG, "rx_bursts: NULL argument");
+    if (cfo_method < 0 || cfo_method > 3) return fail(DSP_E_ARG, "rx_bursts: cfo_method is 0 (f_rel given) or 1..3");
+    if (cfo_method == 0 && !f_rel_in) return fail(DSP_E_ARG, "rx_bursts: cfo_method 0 needs f_rel_in");
+    if (cfo_method != 0 && (!preamble_c128 || n_pre < 2 || n_pre > 4096))
+        return fail(DSP_E_ARG, "rx_bursts: the preamble needs 2..4096 symbols");
+    if (variant != DSP_GARDNER2 && variant != DSP_GARDNER_TED) return fail(DSP_E_ARG, "rx_bursts: bad variant");
+    if (sps < 1) return fail(DSP_E_ARG, "rx_bursts: sps must be >= 1");
+    if (n_taps > n_pkt) return fail(DSP_E_ARG, "rx_bursts: n_taps > n_pkt");
+    if (B > 0x7fffffff || n_pkt > 0x7fffffff) return fail(DSP_E_ARG, "rx_bursts: B or n_pkt too large");
+    if (cfo_method != 0 && (int64_t)(n_pre - 1) * sps + 1 > n_pkt)
+        return fail(DSP_E_ARG, "rx_bursts: the preamble is longer than the packet");
+    int rc = check_cuts("rx_bursts", n, offsets, B, n_pkt);
+    if (rc != DSP_OK) return rc;
+    const size_t eb = dtype == DSP_C128 ? 16 : 8;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    DevBuf d_x, d_o, d_p, d_f, d_cut;
+    HIP_TRY(d_x.alloc((size_t)n * eb)); HIP_TRY(d_o.alloc((size_t)B * 8)); HIP_TRY(d_f.alloc((size_t)B * 24));
+    HIP_TRY(d_cut.alloc((size_t)B * n_pkt * 16));
+    HIP_TRY(hipMemcpyAsync(d_x.p, x, (size_t)n * eb, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_o.p, offsets, (size_t)B * 8, hipMemcpyHostToDevice, s));
+    if (cfo_method == 0) {
+        HIP_TRY(hipMemcpyAsync(d_f.p, f_rel_in, (size_t)B * 8, hipMemcpyHostToDevice, s));
+    } else {
+        HIP_TRY(d_p.alloc((size_t)n_pre * 16));
+        HIP_TRY(hipMemcpyAsync(d_p.p, preamble_c128, (size_t)n_pre * 16, hipMemcpyHostToDevice, s));
+    }
+    rc = dsp_cfo_derotate_dev(c, d_x.p, dtype, n, d_o.as<int64_t>(), B, n_pkt, sps, d_p.as<double>(), n_pre,
+                              cfo_method, d_f.as<double>(), d_cut.as<double>());
+    if (rc != DSP_OK) return rc;
+    const int f_stride = cfo_method == 0 ? 1 : 3;
+    const double *d_fsel = d_f.as<double>() + (cfo_method == 0 ? 0 : cfo_method - 1);
+    if (f_rel_out) {
+        if (f_stride == 1) {
+            HIP_TRY(hipMemcpyAsync(f_rel_out, d_f.p, (size_t)B * 8, hipMemcpyDeviceToHost, s));
+        } else {
+            HIP_TRY(hipMemcpy2DAsync(f_rel_out, 8, d_fsel, 24, 8, (size_t)B, hipMemcpyDeviceToHost, s));
+        }
+    }
+    FirStage S;
+    const bool want_std = normalize_std || std_out;
+    rc = fir_stage(c, S, d_cut.p, DSP_C128, B, n_pkt, n_pkt, nullptr, 0, h, n_taps, -1, want_std, false, true);
+    if (rc != DSP_OK) return rc;
+    if (std_out) HIP_TRY(hipMemcpyAsync(std_out, S.d_std.p, (size_t)B * 8, hipMemcpyDeviceToHost, s));
+    return sync_to_host(c, S.d_tiles.p, DSP_C128, B, n_pkt, S.rows, nullptr,
+                        normalize_std ? S.d_inv.as<double>() : nullptr, sps, alpha, mu0, variant,
+                        interp_half_len, true, Bn, y, nullptr, nullptr, nullptr, rec, err, mu, sig, freq,
+                        ef, dec, n_out, out_stride);
 }
 
 // class FrequencyLockedLoop facade (nco_kernels.hip; parity unpinned: fll.py is absent)

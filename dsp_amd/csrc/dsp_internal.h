@@ -138,5 +138,13 @@ hipError_t launch_stream_copy(const void *src, void *dst, size_t bytes, hipStrea
 hipError_t launch_fll_class(const void *x, int c128, const int *lens, int len_all, int B, int rows, int detector,
                             double Kp, double Ki, double flim, void *out, void *errs, void *freqs, void *phases,
                             double *freq_final, hipStream_t s);
+// cfo_kernels.hip
+hipError_t launch_cfo_preamble(const void *x, bool c128, const int64_t *offsets, int B, int sps, const void *pre,
+                               int L, double *out /* [B][3] */, hipStream_t s);
+hipError_t launch_cfo_fourth_power(const void *x, bool c128, int64_t stride, const int *lens, int len_all, int B,
+                                   int64_t num_samples, double *out, hipStream_t s);
+hipError_t launch_derotate_cut(const void *x, bool c128, const int64_t *offsets, const int64_t *index0,
+                               const double *f, int f_stride, int B, int64_t n_cut, void *out, int64_t out_stride,
+                               hipStream_t s);
 hipError_t launch_diff_corr(const void *x, int c128, int64_t n, int sps, const void *dpre, int L, void *conv,
                             int64_t kstride, hipStream_t s);

@@ -2,13 +2,12 @@
 (worker.py:8-337, QPSK): preamble search -> correlation peaks -> per burst: coarse CFO from the
 preamble, derotation, RRC matched filter + /np.std, Gardner, FLL.
 
-The two loops that cost the reference its run time are device kernels here: the sliding
-normalised differential correlation (``dsp_diff_corr``, worker.py:183-245) and the per-burst
-filter -> Gardner -> FLL chain, which runs for ALL found bursts in one batched call
-(``dsp_rx_chain``, worker.py:299-304).  The glue in between -- peak picking on the correlation
-magnitudes, the phase-slope estimate over the preamble symbols, the derotation -- is a few hundred
-numpy operations per burst and follows the reference line by line, quirks included (the cut offset
-is ``peak // 2`` in both modes, worker.py:276-283).
+The loops that cost the reference its run time are device kernels here: the sliding normalised
+differential correlation (``dsp_diff_corr``, worker.py:183-245) and the whole per-burst body --
+phase-slope CFO estimate over the preamble symbols, cut + derotation, filter -> Gardner -> FLL
+(worker.py:284-304) -- which runs for ALL found bursts in one device call (``dsp_rx_bursts``).
+Peak picking on the correlation magnitudes stays scipy's ``find_peaks`` as in the reference, and
+the quirks are kept (the cut offset is ``peak // 2`` in both modes, worker.py:276-283).
 """
 from __future__ import annotations
 
@@ -16,7 +15,7 @@ import numpy as np
 from scipy.ndimage import shift as array_shift          # worker.py:3
 from scipy.signal import find_peaks                     # worker.py:4
 
-from .api import diff_corr, rrc_filter, rx_chain_batch
+from .api import diff_corr, rrc_filter, rx_bursts
 
 
 class Processing:
@@ -65,21 +64,15 @@ class Processing:
             self.signal, self.preamble, self.sps, self.interp)
         peaks = self.find_conv_peaks(conv_results, conv_results_interp, self.interp)
         n_pkt = len(self.packet_symb) * self.sps
-        bursts = []
         signal_iq = array_shift(self.signal, shift=0.5, mode="nearest") if conv_results_interp else self.signal
-        for peak in peaks:
-            offset = (peak - 1) // 2 if conv_results_interp else peak // 2          # :279-283
-            if offset + n_pkt > len(signal_iq):
-                continue
-            cut = signal_iq[offset:offset + n_pkt]
-            s = cut[::self.sps][:len(self.preamble)]
-            phases = np.angle(s * np.conj(self.preamble))                              # :289-291
-            f_rel = np.mean(np.diff(np.unwrap(phases))) / (2 * np.pi * self.sps)        # :292-294
-            bursts.append(cut * np.exp(-1j * 2 * np.pi * f_rel * (np.arange(len(cut)) + offset)))   # :298
+        offsets = [(peak - 1) // 2 if conv_results_interp else peak // 2 for peak in peaks]      # :279-283
+        offsets = [o for o in offsets if o + n_pkt <= len(signal_iq)]                            # :284-285
         found = []
-        if bursts:
-            X = np.stack(bursts).astype(np.complex128)
-            h = rrc_filter(self.sps, 10, 0.35)                                         # :174
-            out = rx_chain_batch(X, h, self.sps, 0.007, 0.0, 0.03, 1, outputs=("sig",), ctx=self._ctx)   # :299-304
-            found = [out["sig"][b, :int(out["n_out"][b])].copy() for b in range(len(bursts))]
+        self.f_rel = np.zeros(0)
+        if offsets:
+            h = rrc_filter(self.sps, 10, 0.35)                                                   # :174
+            out = rx_bursts(signal_iq, offsets, n_pkt, self.preamble, h, self.sps, 0.007, 0.0, 0.03, 1,
+                            cfo_method=1, outputs=("sig",), ctx=self._ctx)                       # :287-304
+            self.f_rel = out["f_rel"]                                                            # :294
+            found = [out["sig"][b, :int(out["n_out"][b])].copy() for b in range(len(offsets))]
         return peaks, found

@@ -205,6 +205,53 @@ int dsp_fir_tiles_dev(dsp_ctx *ctx, const dsp_fir_args *args);
 int dsp_diff_corr(dsp_ctx *ctx, const void *x, int dtype, int64_t n, const double *preamble_c128, int n_pre,
                   int sps, float *conv_c64, int64_t k_stride);
 
+/* Coarse carrier-frequency estimators.
+ *
+ * dsp_cfo_preamble -- the three preamble-aided estimates of diff_method.py:267-292 (the first is what
+ * worker.Processing.process uses, worker.py:288-294).  For burst b: s = x[offsets[b] :: sps][:n_pre],
+ * p = s * conj(preamble), phases = np.unwrap(np.angle(p));
+ *   f_rel[b][0] = mean(diff(phases))                     / (2 pi sps)
+ *   f_rel[b][1] = polyfit(arange, phases, 1)[0]          / (2 pi sps)      (closed-form LSQ slope)
+ *   f_rel[b][2] = angle(mean(p[1:] * conj(p[:-1])))      / (2 pi sps)
+ * x: n host samples of dtype (DSP_C64 is computed in float64 on the upcast samples); every burst must
+ * hold (n_pre-1)*sps+1 samples from its offset.  All three are float64, cycles per sample.          */
+int dsp_cfo_preamble(dsp_ctx *ctx, const void *x, int dtype, int64_t n, const int64_t *offsets, int64_t B, int sps,
+                     const double *preamble_c128, int n_pre, double *f_rel /* [B][3] */);
+
+/* estimate_initial_frequency(signal, num_samples), estimate_freq.py:4-58, one call per row of a
+ * [B][x_stride] host block: n = min(num_samples, len); z = s[:n]**4; freq = angle(mean(z[1:] *
+ * conj(z[:-1]))) / (8 pi); 0.0 where n < 2.  lens (or NULL = N) gives each row's length.            */
+int dsp_cfo_fourth_power(dsp_ctx *ctx, const void *x, int dtype, int64_t B, int64_t N, int64_t x_stride,
+                         const int32_t *lens, int64_t num_samples, double *freq /* [B] */);
+
+/* Cut + derotate -- worker.py:287,298 / diff_method.py:296-298: out[b][i] = x[offsets[b] + i] *
+ * exp(-1j * 2 pi * f_rel[b] * (i + index0[b])), i < n_cut, complex128 [B][out_stride].
+ * offsets NULL = every cut starts at 0; index0 NULL = offsets (the worker's absolute-index phase).  */
+int dsp_derotate(dsp_ctx *ctx, const void *x, int dtype, int64_t n, const int64_t *offsets, int64_t B,
+                 int64_t n_cut, const double *f_rel, const int64_t *index0, double *out_c128, int64_t out_stride);
+
+/* Device-resident front end of dsp_rx_bursts (asynchronous on the context's stream; every pointer is
+ * device memory): frequency per burst estimated from the preamble (cfo_method 1..3: d_f is [B][3] and
+ * receives all three estimates) or taken from d_f [B] (cfo_method 0), then out[b][i] = x[off_b + i] *
+ * exp(-1j 2 pi f_b (i + off_b)), complex128 [B][n_pkt] -- ready for dsp_fir_tiles_dev (DSP_IN_C128).
+ * The offsets are the caller's responsibility here: 0 <= off_b and off_b + n_pkt <= n.            */
+int dsp_cfo_derotate_dev(dsp_ctx *ctx, const void *d_x, int dtype, int64_t n, const int64_t *d_offsets, int64_t B,
+                         int64_t n_pkt, int sps, const double *d_preamble_c128, int n_pre, int cfo_method,
+                         double *d_f, double *d_out_c128);
+
+/* The per-burst body of worker.Processing.process (worker.py:284-304) for B bursts of one signal in
+ * one call: coarse CFO from the preamble (cfo_method 1..3 as above; 0 = take f_rel_in), cut of n_pkt
+ * samples at offsets[b], derotation with the absolute sample index, RRC 'same' convolution + /np.std
+ * (normalize_std), gardner_timing_recovery, fll_func.  The signal is uploaded once and everything
+ * between stays on the device.  Outputs as dsp_rx_chain (complex128 / float64, any may be NULL);
+ * f_rel_out [B] receives the estimate that was applied.                                              */
+int dsp_rx_bursts(dsp_ctx *ctx, const void *x, int dtype, int64_t n, const int64_t *offsets, int64_t B, int64_t n_pkt,
+                  const double *preamble_c128, int n_pre, int cfo_method, const double *f_rel_in,
+                  const double *h, int n_taps, int normalize_std, int sps, double alpha, double mu0, int variant,
+                  int interp_half_len, double Bn, double y,
+                  void *rec, void *err, void *mu, void *sig, void *freq, void *ef, uint8_t *dec,
+                  int32_t *n_out, int64_t out_stride, double *f_rel_out, double *std_out);
+
 /* Facade for the reference's class FrequencyLockedLoop(detector_method, Kp, Ki, freq_limit)
  * .process_signal(x) (used by fll_real_signal.py:66-74,209-216, f_rel.py:123-132).  PARITY
  * UNPINNED: fll.py itself is absent from the reference, so the loop is this library's own

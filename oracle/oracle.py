@@ -350,3 +350,60 @@ def find_preamble_offset(signal_iq, preamble_iq, sps):
     idx = int(np.argmax(values))
     offset = conv_max[idx][0]
     return offset, signal_iq[offset * sps + idx:], conv_results, conv_max, idx
+
+
+def unwrap(ph):
+    """np.unwrap (period 2*pi, discont pi) restated as the loop it vectorises: the jump between
+    neighbours is folded into [-pi, pi) (a fold of exactly -pi with a positive jump counts as +pi),
+    jumps smaller than pi are left alone, and the corrections accumulate left to right."""
+    ph = np.asarray(ph, dtype=np.float64)
+    up = ph.copy()
+    acc = 0.0
+    for i in range(1, len(ph)):
+        d = ph[i] - ph[i - 1]
+        m = np.fmod(d + np.pi, 2 * np.pi)
+        if m < 0:
+            m += 2 * np.pi
+        m -= np.pi
+        if m == -np.pi and d > 0:
+            m = np.pi
+        acc += 0.0 if abs(d) < np.pi else m - d
+        up[i] = ph[i] + acc
+    return up
+
+
+def preamble_cfo(signal_for_f_rel, preamble_iq, sps):
+    """The three preamble-aided coarse frequency estimates of diff_method.py:267-292 (the first is
+    also worker.py:288-294): phase of s*conj(preamble) -> (1) mean unwrapped phase step, (2) slope of
+    the least-squares line through the unwrapped phases, (3) angle of the mean lag-1 product; each
+    divided by 2*pi*sps (cycles per sample)."""
+    s = np.asarray(signal_for_f_rel, dtype=np.complex128)[:len(preamble_iq)]
+    p = s * np.conj(np.asarray(preamble_iq, dtype=np.complex128)[:len(s)])
+    up = unwrap(np.arctan2(p.imag, p.real))
+    n = np.arange(len(up), dtype=np.float64)
+    m1 = float(np.mean(np.diff(up)))
+    nc, uc = n - n.mean(), up - up.mean()
+    m2 = float(np.sum(nc * uc) / np.sum(nc * nc))            # polyfit(n, up, 1)[0] in closed form
+    q = np.mean(p[1:] * np.conj(p[:-1]))
+    m3 = float(np.arctan2(q.imag, q.real))
+    return np.array([m1, m2, m3]) / (2 * np.pi * sps)
+
+
+def estimate_initial_frequency(signal, num_samples):
+    """estimate_freq.py:4-58: z = s**4 (two squarings), R = mean z[i]*conj(z[i-1]), angle(R)/(8*pi);
+    0.0 for fewer than two samples."""
+    s = np.asarray(signal, dtype=np.complex128)
+    n = min(int(num_samples), len(s))
+    if n < 2:
+        return 0.0
+    z = s[:n] * s[:n]
+    z = z * z
+    r = np.sum(z[1:] * np.conj(z[:-1])) / (n - 1)
+    return float(np.arctan2(r.imag, r.real) / (8 * np.pi))
+
+
+def derotate(x, f_rel, offset=0):
+    """x * exp(-1j*2*pi*f_rel*(arange(len(x)) + offset))  (worker.py:298, diff_method.py:296-298)."""
+    x = np.asarray(x, dtype=np.complex128)
+    th = (2 * np.pi * f_rel) * (np.arange(len(x)) + offset).astype(np.float64)
+    return x * (np.cos(th) - 1j * np.sin(th))
