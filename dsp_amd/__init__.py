@@ -15,7 +15,8 @@ from .api import (rrc_filter, fll_gains, interpolate_sample, gardner_timing_reco
                   rx_chain_batch, sync_capture_segmented, lagrange_resample,
                   apply_fractional_shift, FrequencyLockedLoop, diff_corr, find_preamble_offset,
                   find_optimal_sampling_phase, preamble_cfo, estimate_initial_frequency,
-                  estimate_initial_frequency_batch, derotate, rx_bursts)
+                  estimate_initial_frequency_batch, derotate, rx_bursts, constellation_points,
+                  fll_slicer_batch, fll_func_constellation, decide_symbols)
 
 __all__ = [
     "Context", "DspError", "default_context", "build", "lib",
@@ -25,4 +26,5 @@ __all__ = [
     "read_iq_int16", "read_iq_int16_words", "read_iq_float32", "fir_batch", "filter_samples",
     "rx_chain_batch", "sync_capture_segmented", "lagrange_resample", "apply_fractional_shift", "FrequencyLockedLoop", "diff_corr", "find_preamble_offset", "find_optimal_sampling_phase",
     "preamble_cfo", "estimate_initial_frequency", "estimate_initial_frequency_batch", "derotate", "rx_bursts",
+    "constellation_points", "fll_slicer_batch", "fll_func_constellation", "decide_symbols",
 ]

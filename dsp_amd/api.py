@@ -608,3 +608,77 @@ def rx_bursts(signal_iq, offsets, n_pkt, preamble_iq, taps, sps=4, alpha=0.007, 
         break
     bufs.update(n_out=n_out, std=std, f_rel=fout)
     return bufs
+
+
+# ---------------------------------------------------------------------------
+# the constellation switch of worker.Processing.fll_func / decision_direct
+CONSTELLATIONS = ("bpsk", "qpsk", "8psk", "16psk", "16apsk")
+
+
+def constellation_points(constellation):
+    """Decision points in the reference's order: the tables of worker.py:40,49,58-60; for the sign
+    slicers the values a decision index maps to (bpsk: +1, -1, 0; qpsk: quadrant order)."""
+    if constellation == "bpsk":
+        return np.array([1, -1, 0], np.complex128)
+    if constellation == "qpsk":
+        return np.array([1 + 1j, -1 + 1j, 1 - 1j, -1 - 1j]) / np.sqrt(2)
+    if constellation == "8psk":
+        return np.exp(1j * (np.pi / 4 * np.arange(8) - np.pi))
+    if constellation == "16psk":
+        return np.exp(1j * (np.pi / 8 * np.arange(16) - np.pi))
+    if constellation == "16apsk":
+        inner_ring = 0.5 * np.exp(1j * (np.pi / 4 + np.arange(4) * np.pi / 2))
+        outer_ring = 1 * np.exp(1j * (np.pi / 12 + np.arange(12) * np.pi / 6))
+        return np.concatenate([inner_ring, outer_ring])
+    raise ValueError(f"unknown constellation {constellation!r}")
+
+
+def fll_slicer_batch(x, Bn=0.001, y=1, constellation="qpsk", *, lens=None, outputs="all", ctx=None):
+    """worker.Processing.fll_func (worker.py:18-78) on [B, M] bursts at one sample per symbol.
+    Returns a dict: sig / freq / ef [B, M] (x's precision), dec uint8 decision indices into
+    constellation_points(constellation), curr_freq float64[B]."""
+    ctx = ctx or default_context()
+    x, dt, rdt = _as_bursts(x)
+    B, M = x.shape
+    kind = 0 if constellation == "bpsk" else (1 if constellation == "qpsk" else 2)
+    pts = np.ascontiguousarray(constellation_points(constellation), dtype=np.complex128) if kind == 2 else None
+    names = ("sig", "freq", "ef", "dec") if outputs == "all" else tuple(outputs)
+    bufs = {}
+    for nm in names:
+        bufs[nm] = np.zeros((B, M), dtype=x.dtype if nm == "sig" else (np.uint8 if nm == "dec" else rdt))
+    cf = np.zeros(B, np.float64)
+    g = lambda nm: _vp(bufs.get(nm))  # noqa: E731
+    check(_lib.lib().dsp_fll_slicer(ctx.handle, _vp(x), dt, B, M, M, _vp(_lens(lens, B, M)), kind, _vp(pts),
+                                   pts.size if pts is not None else 0, float(Bn), float(y),
+                                   g("sig"), g("freq"), g("ef"), g("dec"), M, _vp(cf)))
+    bufs["curr_freq"] = cf
+    return bufs
+
+
+def fll_func_constellation(signal, Bn=0.001, y=1, constellation="qpsk", *, ctx=None):
+    """worker.Processing.fll_func(signal, Bn, y) for self.constellation (worker.py:18-78):
+    (signal_list complex128, curr_freq float, curr_freq_list, ef_n_list)."""
+    x = np.asarray(signal)
+    n = x.size
+    if n == 0:
+        return np.zeros(0, complex), 0, np.zeros(0), np.zeros(0)
+    o = fll_slicer_batch(x.reshape(1, -1).astype(np.complex128, copy=False), Bn, y, constellation,
+                         outputs=("sig", "freq", "ef"), ctx=ctx)
+    return o["sig"][0], float(o["curr_freq"][0]), o["freq"][0], o["ef"][0]
+
+
+def decide_symbols(signal_list, constellation="qpsk", *, ctx=None):
+    """The slicer of decision_direct (worker.py:84-123): (decided complex64 points, indices)."""
+    x = np.asarray(signal_list)
+    if x.size == 0:
+        return np.zeros(0, np.complex64), np.zeros(0, np.uint8)
+    o = fll_slicer_batch(x.reshape(1, -1).astype(np.complex128, copy=False), 0.0, 1, constellation,
+                         outputs=("dec",), ctx=ctx)
+    idx = o["dec"][0]
+    pts = constellation_points(constellation)
+    if constellation == "qpsk":
+        # a zero component decides 0 in that component (np.sign(0) = 0), which no quadrant encodes
+        d = (np.sign(x.real) + 1j * np.sign(x.imag)) / np.sqrt(2)
+        zero = (x.real == 0) | (x.imag == 0)
+        return np.where(zero, d, pts[idx]).astype(np.complex64), idx
+    return pts[idx].astype(np.complex64), idx

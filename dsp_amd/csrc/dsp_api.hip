@@ -802,6 +802,70 @@ int dsp_diff_corr(dsp_ctx *c, const void *x, int dtype, int64_t n, const double 
     return DSP_OK;
 }
 
+// fll_func with worker.Processing's constellation switch (nco_kernels.hip fll_slicer_kernel)
+int dsp_fll_slicer(dsp_ctx *c, const void *x, int dtype, int64_t B, int64_t N, int64_t x_stride,
+                   const int32_t *lens, int kind, const double *points_c128, int n_points, double Bn, double y,
+                   void *out, void *freq, void *ef, uint8_t *dec, int64_t out_stride, double *curr_freq)
+{
+    if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    if (B < 0 || N < 0) return fail(DSP_E_ARG, "negative B or N");
+    if (B == 0 || N == 0) {
+        if (curr_freq) for (int64_t b = 0; b < B; b++) curr_freq[b] = 0.0;
+        return DSP_OK;
+    }
+    if (!x) return fail(DSP_E_ARG, "x is NULL");
+    if (dtype != DSP_C64 && dtype != DSP_C128) return fail(DSP_E_ARG, "bad dtype");
+    if (kind < 0 || kind > 2) return fail(DSP_E_ARG, "fll_slicer: kind must be 0 bpsk, 1 qpsk, 2 table");
+    if (kind == 2 && (!points_c128 || n_points < 1 || n_points > 64))
+        return fail(DSP_E_ARG, "fll_slicer: the table needs 1..64 points");
+    if (x_stride < N || out_stride < N) return fail(DSP_E_ARG, "stride < N");
+    if (lens)
+        for (int64_t b = 0; b < B; b++)
+            if (lens[b] < 0 || lens[b] > N) return fail(DSP_E_ARG, "lens[%lld] out of range", (long long)b);
+    double kp, ki;
+    int rc = dsp_fll_gains(Bn, y, &kp, &ki);
+    if (rc != DSP_OK) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    const int ce = dtype == DSP_C128 ? 16 : 8, re = ce / 2;
+    const int64_t rows = dsp_tile_rows(N), ntiles = (B + 63) / 64;
+    hipStream_t s = c->stream;
+    DevBuf d_x, d_xt, d_lens, d_ff, d_stage, d_pts;
+    HIP_TRY(d_x.alloc((size_t)B * x_stride * ce));
+    HIP_TRY(d_xt.alloc((size_t)ntiles * rows * 64 * ce));
+    HIP_TRY(hipMemcpyAsync(d_x.p, x, (size_t)B * x_stride * ce, hipMemcpyHostToDevice, s));
+    if (lens) {
+        HIP_TRY(d_lens.alloc((size_t)B * 4));
+        HIP_TRY(hipMemcpyAsync(d_lens.p, lens, (size_t)B * 4, hipMemcpyHostToDevice, s));
+    }
+    if (kind == 2) {
+        HIP_TRY(d_pts.alloc((size_t)n_points * 16));
+        HIP_TRY(hipMemcpyAsync(d_pts.p, points_c128, (size_t)n_points * 16, hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(launch_tile_from_bursts(d_x.p, x_stride, d_lens.as<int>(), (int)N, (int)B, d_xt.p, (int)rows, ce, s));
+    struct OutSpec { void *host; int elem; DevBuf tiles; };
+    OutSpec outs[4] = {{out, ce, {}}, {freq, re, {}}, {ef, re, {}}, {dec, 1, {}}};
+    for (auto &o : outs)
+        if (o.host) {
+            HIP_TRY(o.tiles.alloc((size_t)ntiles * rows * 64 * o.elem));
+            HIP_TRY(hipMemsetAsync(o.tiles.p, 0, (size_t)ntiles * rows * 64 * o.elem, s));
+        }
+    HIP_TRY(d_ff.alloc((size_t)B * 8));
+    HIP_TRY(launch_fll_slicer(d_xt.p, dtype == DSP_C128, d_lens.as<int>(), (int)N, (int)B, (int)rows, kind, d_pts.p,
+                              kind == 2 ? n_points : 0, kp, ki, outs[0].tiles.p, outs[1].tiles.p, outs[2].tiles.p,
+                              outs[3].tiles.as<unsigned char>(), d_ff.as<double>(), s));
+    HIP_TRY(d_stage.alloc((size_t)B * out_stride * ce));
+    for (auto &o : outs) {
+        if (!o.host) continue;
+        HIP_TRY(hipMemsetAsync(d_stage.p, 0, (size_t)B * out_stride * o.elem, s));
+        HIP_TRY(launch_bursts_from_tiles(o.tiles.p, (int)rows, (int)B, d_stage.p, out_stride, (int)N, o.elem, s));
+        HIP_TRY(hipMemcpyAsync(o.host, d_stage.p, (size_t)B * out_stride * o.elem, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    if (curr_freq) HIP_TRY(hipMemcpyAsync(curr_freq, d_ff.p, (size_t)B * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return DSP_OK;
+}
+
 // ---- coarse CFO estimators + burst cutter (cfo_kernels.hip) --------------------
 static int check_cuts(const char *who, int64_t n, const int64_t *offsets, int64_t B, int64_t span)
 {

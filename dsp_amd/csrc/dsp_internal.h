@@ -138,6 +138,9 @@ hipError_t launch_stream_copy(const void *src, void *dst, size_t bytes, hipStrea
 hipError_t launch_fll_class(const void *x, int c128, const int *lens, int len_all, int B, int rows, int detector,
                             double Kp, double Ki, double flim, void *out, void *errs, void *freqs, void *phases,
                             double *freq_final, hipStream_t s);
+hipError_t launch_fll_slicer(const void *x, int c128, const int *lens, int len_all, int B, int rows, int kind,
+                             const void *points, int n_points, double kp, double ki, void *out, void *freqs,
+                             void *efs, unsigned char *dec, double *freq_final, hipStream_t s);
 // cfo_kernels.hip
 hipError_t launch_cfo_preamble(const void *x, bool c128, const int64_t *offsets, int B, int sps, const void *pre,
                                int L, double *out /* [B][3] */, hipStream_t s);

@@ -87,6 +87,91 @@ __global__ __launch_bounds__(64) void fll_class_kernel(const IN *__restrict__ x,
     if (b < B && freq_final) freq_final[b] = len > 0 ? facc / (double)(len - tail0) : 0.0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// fll_func with the constellation switch of worker.Processing.fll_func (worker.py:18-78; SURVEY.md
+// 8f rank 4).  The loop is fll_func.py's (absolute-index phase 2 pi f i, PI filter kp / ki); only
+// the slicer changes:
+//   kind 0  bpsk    decided = sign(Re) + 0j                                        :36
+//   kind 1  qpsk    decided = (sign(Re) + j sign(Im)) / sqrt(2)                    :38
+//   kind 2  table   the point of `points` nearest to the sample, np.abs distance, the first of
+//                   equally near points wins (strict <)                            :40-66
+// error = angle(sample * conj(decided)) for all of them (:70).  dec receives the decision index:
+// table position; qpsk quadrant (Re<0) + 2 (Im<0); bpsk 0 / 1 / 2 for Re > 0 / < 0 / == 0.
+// One lane per burst over the tiled layout; the table (<= 64 points) sits in LDS.
+// np.abs of a complex128 as numpy 2.2 computes it on an FMA-capable host (checked bit for bit on 2e6
+// random values, tests/golden/make_golden_slicers.py environment): big * sqrt(fma(r, r, 1)) with
+// r = small / big -- NOT a correctly rounded hypot.  The nearest-point search compares these values,
+// so (nearly) equidistant points resolve exactly as in the reference.
+__device__ __forceinline__ double abs_np(double a, double b)
+{
+    double x = __builtin_fabs(a), y = __builtin_fabs(b);
+    if (x < y) { const double t = x; x = y; y = t; }
+    if (x == 0.0) return 0.0;
+    const double r = y / x;
+    return x * __builtin_sqrt(__builtin_fma(r, r, 1.0));
+}
+
+template <typename IN, typename OS, typename OC>
+__global__ __launch_bounds__(64) void fll_slicer_kernel(const IN *__restrict__ x, const int *__restrict__ lens,
+                                                        int len_all, int B, int rows, int kind,
+                                                        const d2v *__restrict__ points, int n_points, double kp,
+                                                        double ki, OC *__restrict__ out, OS *__restrict__ freqs,
+                                                        OS *__restrict__ efs, unsigned char *__restrict__ dec,
+                                                        double *__restrict__ freq_final)
+{
+    __shared__ d2v tab[64];
+    const int lane = threadIdx.x, tile = blockIdx.x, b = tile * 64 + lane;
+    if (lane < n_points) tab[lane] = points[lane];
+    __syncthreads();
+    const int len = b < B ? (lens ? lens[b] : len_all) : 0;
+    int max_len = len;
+    for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(max_len, d); max_len = o > max_len ? o : max_len; }
+    dspm::MathK K;
+    for (int i = 0; i < dspm::K_COUNT; i++) K.v[i] = k_nco_table[i];
+    const size_t base = (size_t)tile * rows * 64 + lane;
+    double curr_freq = 0.0, integ = 0.0;
+    for (int n = 0; n < max_len; n++) {
+        const IN v = x[base + (size_t)n * 64];
+        const bool live = n < len;
+        const double xr = (double)v.x, xi = (double)v.y;
+        const double phase = K.v[dspm::K_TWO_PI] * curr_freq * (double)n;       // :31
+        double s, c;
+        dspm::sincos_f64(K, phase, s, c);
+        const double sr = xr * c + xi * s, si = xi * c - xr * s;                 // :32
+        double dr, di;
+        int idx;
+        if (kind == 0) {
+            dr = sr > 0.0 ? 1.0 : (sr < 0.0 ? -1.0 : 0.0); di = 0.0;
+            idx = sr > 0.0 ? 0 : (sr < 0.0 ? 1 : 2);
+        } else if (kind == 1) {
+            dr = sr > 0.0 ? K.v[dspm::K_SCL] : (sr < 0.0 ? -K.v[dspm::K_SCL] : 0.0);
+            di = si > 0.0 ? K.v[dspm::K_SCL] : (si < 0.0 ? -K.v[dspm::K_SCL] : 0.0);
+            idx = (int)(sr < 0.0) + 2 * (int)(si < 0.0);
+        } else {
+            double best = __builtin_inf();
+            idx = 0;
+            for (int j = 0; j < n_points; j++) {
+                const double dist = abs_np(tab[j].x - sr, tab[j].y - si);         // np.abs(d - sample)
+                if (dist < best) { best = dist; idx = j; }
+            }
+            dr = tab[idx].x; di = tab[idx].y;
+        }
+        const double zr = sr * dr + si * di, zi = si * dr - sr * di;             // sample * conj(decided)
+        const double error = dspm::atan2_f64(K, zi, zr, false);                  // :70
+        if (live) {
+            integ += error * ki;                                                 // :71
+            const double ef_n = error * kp + integ;                              // :72
+            curr_freq += ef_n;                                                   // :74
+            const size_t at = base + (size_t)n * 64;
+            if (out) out[at] = OC{(OS)sr, (OS)si};
+            if (freqs) freqs[at] = (OS)curr_freq;
+            if (efs) efs[at] = (OS)ef_n;
+            if (dec) dec[at] = (unsigned char)idx;
+        }
+    }
+    if (b < B && freq_final) freq_final[b] = curr_freq;
+}
+
 }  // namespace
 
 hipError_t launch_fll_class(const void *x, int c128, const int *lens, int len_all, int B, int rows, int detector,
@@ -103,5 +188,22 @@ hipError_t launch_fll_class(const void *x, int c128, const int *lens, int len_al
         hipLaunchKernelGGL((fll_class_kernel<f2v, float, f2v>), dim3(nt), dim3(64), 0, s, (const f2v *)x, lens, len_all,
                            B, rows, detector, Kp, Ki, flim, (f2v *)out, (float *)errs, (float *)freqs,
                            (float *)phases, freq_final);
+    return hipGetLastError();
+}
+
+hipError_t launch_fll_slicer(const void *x, int c128, const int *lens, int len_all, int B, int rows, int kind,
+                             const void *points, int n_points, double kp, double ki, void *out, void *freqs,
+                             void *efs, unsigned char *dec, double *freq_final, hipStream_t s)
+{
+    if (B <= 0) return hipSuccess;
+    const int nt = (B + 63) / 64;
+    if (c128)
+        hipLaunchKernelGGL((fll_slicer_kernel<d2v, double, d2v>), dim3(nt), dim3(64), 0, s, (const d2v *)x, lens,
+                           len_all, B, rows, kind, (const d2v *)points, n_points, kp, ki, (d2v *)out, (double *)freqs,
+                           (double *)efs, dec, freq_final);
+    else
+        hipLaunchKernelGGL((fll_slicer_kernel<f2v, float, f2v>), dim3(nt), dim3(64), 0, s, (const f2v *)x, lens,
+                           len_all, B, rows, kind, (const d2v *)points, n_points, kp, ki, (f2v *)out, (float *)freqs,
+                           (float *)efs, dec, freq_final);
     return hipGetLastError();
 }

@@ -15,14 +15,14 @@ import numpy as np
 from scipy.ndimage import shift as array_shift          # worker.py:3
 from scipy.signal import find_peaks                     # worker.py:4
 
-from .api import diff_corr, rrc_filter, rx_bursts
+from .api import (CONSTELLATIONS, decide_symbols, diff_corr, fll_func_constellation, rrc_filter, rx_bursts)
 
 
 class Processing:
     def __init__(self, signal=None, preamble=None, packet_symb=None, sps=4, constellation="qpsk", interp=False,
                  *, ctx=None):
-        if constellation != "qpsk":
-            raise ValueError("only the QPSK receiver is built (SURVEY.md 8f rank 4)")
+        if constellation not in CONSTELLATIONS:
+            raise ValueError(f"constellation must be one of {CONSTELLATIONS}")
         self.signal = signal
         self.preamble = preamble
         self.packet_symb = packet_symb      # preamble + payload symbols of one packet
@@ -30,6 +30,29 @@ class Processing:
         self.constellation = constellation
         self.interp = interp
         self._ctx = ctx
+
+    # worker.py:18-78
+    def fll_func(self, signal, Bn=0.001, y=1):
+        return fll_func_constellation(signal, Bn, y, self.constellation, ctx=self._ctx)
+
+    # worker.py:80-170.  The reference prints the match percentages and returns nothing; here the
+    # decided symbols are returned and the percentages kept in self.match_rates:
+    # [(None, pct without rotation), (degrees, pct) per trial rotation].
+    def decision_direct(self, signal_list):
+        decision_direct, _ = decide_symbols(signal_list, self.constellation, ctx=self._ctx)     # :120-123
+        self.match_rates = []
+        if self.packet_symb is not None and len(self.packet_symb) == len(decision_direct):     # :129-130
+            ref = np.asarray(self.packet_symb)
+            n = len(decision_direct)
+            self.match_rates.append((None, np.count_nonzero(
+                np.isclose(decision_direct, ref, rtol=1e-5, atol=1e-5)) / n * 100))             # :137-142
+            num_phases, phase_step = {"qpsk": (4, np.pi / 2), "8psk": (8, np.pi / 4),
+                                      "16psk": (16, np.pi / 8)}.get(self.constellation, (16, 2 * np.pi / 16))
+            for phase in range(num_phases):                                                     # :158-170
+                shifted = decision_direct * np.exp(1j * phase_step * phase)
+                cnt = np.count_nonzero(np.isclose(shifted, ref, rtol=1e-5, atol=1e-5))
+                self.match_rates.append((float(np.degrees(phase_step * phase)), cnt / n * 100))
+        return decision_direct
 
     # worker.py:180-245
     def find_preamble_offset_with_interpolate_dots(self, signal_iq, preamble_iq, sps, interp=False):
@@ -71,8 +94,13 @@ class Processing:
         self.f_rel = np.zeros(0)
         if offsets:
             h = rrc_filter(self.sps, 10, 0.35)                                                   # :174
+            qpsk = self.constellation == "qpsk"        # the fused Gardner+FLL kernel slices QPSK
             out = rx_bursts(signal_iq, offsets, n_pkt, self.preamble, h, self.sps, 0.007, 0.0, 0.03, 1,
-                            cfo_method=1, outputs=("sig",), ctx=self._ctx)                       # :287-304
+                            cfo_method=1, outputs=("sig",) if qpsk else ("rec",), ctx=self._ctx)   # :287-304
             self.f_rel = out["f_rel"]                                                            # :294
-            found = [out["sig"][b, :int(out["n_out"][b])].copy() for b in range(len(offsets))]
+            key = "sig" if qpsk else "rec"
+            found = [out[key][b, :int(out["n_out"][b])].copy() for b in range(len(offsets))]
+            if not qpsk:
+                found = [self.fll_func(rec, Bn=0.03)[0] for rec in found]                        # :304
+            self.decisions = [self.decision_direct(s) for s in found]                            # :332
         return peaks, found

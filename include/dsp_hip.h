@@ -205,6 +205,18 @@ int dsp_fir_tiles_dev(dsp_ctx *ctx, const dsp_fir_args *args);
 int dsp_diff_corr(dsp_ctx *ctx, const void *x, int dtype, int64_t n, const double *preamble_c128, int n_pre,
                   int sps, float *conv_c64, int64_t k_stride);
 
+/* fll_func with the constellation switch of worker.Processing.fll_func (worker.py:18-78; SURVEY.md 8f
+ * rank 4): the loop of fll_func.py with the slicer chosen by kind -- 0 bpsk sign(Re) + 0j (:36),
+ * 1 qpsk (:38), 2 nearest point of points_c128[n_points] by np.abs distance, first of equally near
+ * points wins (:40-66; 8psk / 16psk / 16apsk tables are built by the caller exactly as the reference
+ * does).  x: [B][x_stride] host bursts at 1 sample/symbol.  Outputs [B][out_stride] in x's precision
+ * (out complex, freq / ef real; any may be NULL), dec uint8 decision index (table position; qpsk
+ * quadrant (Re<0)+2(Im<0); bpsk 0 / 1 / 2 for Re > 0 / < 0 / == 0), curr_freq [B] the final frequency.
+ * Bn = 0 freezes the loop: dec is then decision_direct's slicer alone (worker.py:80-123).           */
+int dsp_fll_slicer(dsp_ctx *ctx, const void *x, int dtype, int64_t B, int64_t N, int64_t x_stride,
+                   const int32_t *lens, int kind, const double *points_c128, int n_points, double Bn, double y,
+                   void *out, void *freq, void *ef, uint8_t *dec, int64_t out_stride, double *curr_freq);
+
 /* Coarse carrier-frequency estimators.
  *
  * dsp_cfo_preamble -- the three preamble-aided estimates of diff_method.py:267-292 (the first is what

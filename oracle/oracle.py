@@ -407,3 +407,60 @@ def derotate(x, f_rel, offset=0):
     x = np.asarray(x, dtype=np.complex128)
     th = (2 * np.pi * f_rel) * (np.arange(len(x)) + offset).astype(np.float64)
     return x * (np.cos(th) - 1j * np.sin(th))
+
+
+def constellation_points(constellation):
+    """The decision tables of worker.Processing.fll_func (worker.py:40,49,58-60); None for the
+    sign slicers (bpsk :36, qpsk :38)."""
+    if constellation == "8psk":
+        return np.exp(1j * (np.pi / 4 * np.arange(8) - np.pi))
+    if constellation == "16psk":
+        return np.exp(1j * (np.pi / 8 * np.arange(16) - np.pi))
+    if constellation == "16apsk":
+        inner = 0.5 * np.exp(1j * (np.pi / 4 + np.arange(4) * np.pi / 2))
+        outer = 1 * np.exp(1j * (np.pi / 12 + np.arange(12) * np.pi / 6))
+        return np.concatenate([inner, outer])
+    if constellation in ("bpsk", "qpsk"):
+        return None
+    raise ValueError(constellation)
+
+
+def decide_symbol(sample, constellation, table=None):
+    """worker.py:35-66 / :84-118 -> (decided point, index).  Index: table position (first of the
+    nearest points wins, strict <); bpsk 0 / 1 / 2 for Re > 0 / < 0 / == 0; qpsk quadrant
+    (Re<0) + 2 (Im<0) (the parity object of a7; zero components decide 0 there)."""
+    if constellation == "bpsk":
+        s = np.sign(sample.real)
+        return complex(s, 0.0), (0 if s > 0 else (1 if s < 0 else 2))
+    if constellation == "qpsk":
+        d = (np.sign(sample.real) + 1j * np.sign(sample.imag)) / np.sqrt(2)
+        return d, int(sample.real < 0) + 2 * int(sample.imag < 0)
+    best, arg = np.inf, 0
+    for j, d in enumerate(table):
+        dist = np.abs(d - sample)
+        if dist < best:
+            best, arg = dist, j
+    return table[arg], arg
+
+
+def fll_func_constellation(signal, Bn=0.001, y=1, constellation="qpsk"):
+    """worker.Processing.fll_func (worker.py:18-78) restated loop for loop (small inputs only).
+    Returns (signal_list, curr_freq, curr_freq_list, ef_n_list, decision_index)."""
+    signal = np.asarray(signal, dtype=np.complex128)
+    table = constellation_points(constellation)
+    kp = 4 * Bn / 1000 / (y + 1 / (4 * y))
+    ki = 4 * (Bn / 1000 / (y + 1 / (4 * y))) ** 2
+    n = len(signal)
+    out = np.zeros(n, np.complex128); fr = np.zeros(n); ef = np.zeros(n); dec = np.zeros(n, np.uint8)
+    curr_freq, integrator = 0.0, 0.0
+    for i in range(n):
+        phase = 2 * np.pi * curr_freq * i
+        s = signal[i] * complex(np.cos(phase), -np.sin(phase))
+        d, k = decide_symbol(s, constellation, table)
+        z = s * np.conj(d)
+        error = float(np.arctan2(z.imag, z.real))
+        integrator += error * ki
+        e = error * kp + integrator
+        curr_freq += e
+        out[i] = s; fr[i] = curr_freq; ef[i] = e; dec[i] = k
+    return out, curr_freq, fr, ef, dec

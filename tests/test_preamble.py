@@ -100,3 +100,26 @@ def test_gpu_worker_processing(ctx, interp):
         assert np.max(np.abs(s - ref)) < 1e-9
         quad = lambda z: (z.real < 0).astype(np.uint8) + 2 * (z.imag < 0)      # noqa: E731
         assert np.array_equal(quad(s), quad(ref))
+
+
+@pytest.mark.gpu
+def test_generation_reproduces_reference(tmp_path):
+    """worker.Generation (worker.py:339-427) with the same seed: identical symbols (same numpy draws),
+    samples equal to the reference's up to the device filter's rounding; the PCM writer round-trips."""
+    import dsp_amd
+    from dsp_amd.generation import Generation, save_as_pcm_float32_iq
+    gw = np.load(os.path.join(GOLDEN, "g_worker.npz"))
+    np.random.seed(20251114)
+    gen = Generation(constellation="qpsk", preamble_length=64, signal_length=400, sps=4, Frel=0.0004,
+                     Noise_power=0.02, N=3, Delay=30)
+    pre, samples, symbols = gen.generate()
+    assert np.array_equal(pre, gw["w_pre"]) and np.array_equal(symbols, gw["w_symbols"])
+    assert samples.dtype == np.complex128 and samples.shape == gw["w_samples"].shape
+    assert np.abs(samples - gw["w_samples"]).max() < 1e-12
+    for c in ("bpsk", "8psk", "16psk", "16apsk"):
+        p, s, y = Generation(c, 16, 40, 4, 1e-4, 0.01, 2, 5).generate()
+        assert len(p) == 16 and len(y) == 40 and len(s) == (5 + 2 * 45) * 4
+    path = str(tmp_path / "x.pcm")
+    save_as_pcm_float32_iq(samples, path)
+    back = dsp_amd.read_iq_float32(path)
+    assert np.array_equal(back, samples.astype(np.complex64))
