@@ -59,9 +59,20 @@ def cpu_baseline(X, seconds=12.0):
         counts = list(ex.map(work, range(cores)))
     dt = time.perf_counter() - t0
     bursts = sum(counts)
+    # the reference's own speed class: the same two loops written in its idiom (numpy scalars and
+    # ufunc calls per sample, oracle/py_loops.py) on one core -- the reference itself cannot travel
+    from oracle import py_loops as P
+    nb = min(6, X.shape[0])
+    t1 = time.perf_counter()
+    for b in range(nb):
+        rec, _, _ = P.gardner_np(X[b].astype(np.complex128), SPS, ALPHA, 0.0)
+        P.fll_np(rec, BN, Y)
+    dp = time.perf_counter() - t1
     return {"value": bursts * N / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
             "sample": f"{bursts} bursts x {N} samples (oracle Gardner+FLL+decisions, fp64 C, "
-                      f"{cores} threads, {dt:.1f} s)"}
+                      f"{cores} threads, {dt:.1f} s)",
+            "reference_idiom_python": {"value": nb * N / dp / 1e6, "unit": "Msamples/s", "cores": 1,
+                                       "sample": f"{nb} bursts, numpy-scalar loops as the reference writes them"}}
 
 
 def main():

@@ -1178,7 +1178,9 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
     HIP_TRY(d_nout.alloc((size_t)S * 4)); HIP_TRY(d_status.alloc((size_t)S * 4));
     HIP_TRY(d_j0.alloc((size_t)S * 4)); HIP_TRY(d_j1.alloc((size_t)S * 4)); HIP_TRY(d_rot.alloc((size_t)S * 4));
     HIP_TRY(d_pl.alloc((size_t)S * 8)); HIP_TRY(d_off.alloc((size_t)(S + 1) * 8));
-    HIP_TRY(hipMemsetAsync(d_tiles.p, 0, (size_t)ntiles * rows * 64 * 8, st));
+    // the filter pass writes every row of every lane (zeros past a window's end and in the idle lanes
+    // of the last tile: its chunks cover ceil(Nw / CH) * CH >= rows); only the copy path needs clearing
+    if (!a->h) HIP_TRY(hipMemsetAsync(d_tiles.p, 0, (size_t)ntiles * rows * 64 * 8, st));
 
     // ---- windows -> tiles (optionally through the matched filter) ------------------------
     DevBuf d_peak, d_c64, d_ws, d_inv, d_lo, d_hi, d_part;

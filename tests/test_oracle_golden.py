@@ -184,3 +184,20 @@ def test_fll_chaos_beyond_horizon(oracle):
     assert np.array_equal(qa[:3300], qb[:3300])
     assert np.max(np.abs(a[2][:3300] - b[2][:3300])) < 1e-12
     assert np.sum(qa[5000:] != qb[5000:]) > 1000
+
+
+def test_py_loops_match_reference_vectors():
+    """oracle/py_loops.py (the interpreter-bound speed proxies bench.py times) against the
+    reference's own outputs on a golden synthetic burst: Gardner bit-exact, FLL to 1e-15."""
+    from oracle import py_loops as P
+    g = golden("g_synth_bursts")
+    y = g["y"][0]
+    n = int(g["n_rec"][0])
+    for gard, fll in ((P.gardner_np, P.fll_np), (P.gardner, P.fll)):
+        rec, err, mu = gard(y if gard is P.gardner_np else y.tolist(), 4, 0.007, 0.0)
+        out, f, fr, ef = fll(rec, 0.03, 1)              # lists stay lists for the plain-Python pair
+        rec, mu = np.asarray(rec), np.asarray(mu)
+        assert len(rec) == n
+        assert np.array_equal(rec, g["rec"][0][:n]) and np.array_equal(mu, g["mu"][0][:n - 1])
+        assert np.abs(np.asarray(out) - g["fll_out"][0][:n]).max() < 1e-14
+        assert np.abs(np.asarray(fr) - g["fll_freq"][0][:n]).max() < 1e-15
