@@ -38,6 +38,7 @@ class SyncArgs(C.Structure):
         ("rec", C.c_void_p), ("err", C.c_void_p), ("mu", C.c_void_p), ("sig", C.c_void_p),
         ("freq", C.c_void_p), ("ef", C.c_void_p), ("dec", C.c_void_p),
         ("out_rows", C.c_int64), ("n_out", C.c_void_p), ("status", C.c_void_p), ("pos", C.c_void_p),
+        ("mu0_per", C.c_void_p),
     ]
 
 
@@ -62,6 +63,7 @@ class CaptureArgs(C.Structure):
         ("seg_len", C.c_int64), ("warmup", C.c_int64),
         ("dec", C.c_void_p), ("mu", C.c_void_p), ("freq", C.c_void_p),
         ("capacity", C.c_int64), ("n_symbols", C.c_void_p), ("seg_info", C.c_void_p),
+        ("acquire", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

@@ -333,7 +333,7 @@ def rx_chain_batch(x, taps, sps=4, alpha=0.007, mu_initial=0.0, Bn=0.03, y=1, *,
 
 def sync_capture_segmented(x, sps=4, alpha=0.007, mu_initial=0.0, Bn=0.003, y=1, *, taps=None,
                            seg_len=65536, warmup=4096, normalize=True, want=("dec", "mu", "freq"),
-                           ctx=None):
+                           acquire=True, ctx=None):
     """Segment-parallel Gardner + FLL + decisions over ONE long capture (no reference
     counterpart; north-star (c), include/dsp_hip.h dsp_sync_capture_segmented).
 
@@ -342,6 +342,8 @@ def sync_capture_segmented(x, sps=4, alpha=0.007, mu_initial=0.0, Bn=0.003, y=1,
     np.std over the whole capture (worker.py:173-178), None when x is already filtered.
     Returns a dict: dec uint8[n] quadrant indices, mu / freq float32[n] if wanted,
     seg_info int32[S, 4] = (first kept row, end row, rotation, rows produced) per segment.
+    acquire (default): every window starts its timing loop at the sampling phase whose strobes carry
+    the most energy over its first 256 symbols (mu_initial is then unused); False: at mu_initial.
     """
     ctx = ctx or default_context()
     x = np.asarray(x)
@@ -371,7 +373,7 @@ def sync_capture_segmented(x, sps=4, alpha=0.007, mu_initial=0.0, Bn=0.003, y=1,
         h = np.ascontiguousarray(taps, dtype=np.float64)
         a.h = h.ctypes.data; a.n_taps = h.size
     a.sps = int(sps); a.alpha = float(alpha); a.mu0 = float(mu_initial); a.Bn = float(Bn); a.y = float(y)
-    a.seg_len = int(seg_len); a.warmup = int(warmup)
+    a.seg_len = int(seg_len); a.warmup = int(warmup); a.acquire = int(bool(acquire))
     a.dec = dec.ctypes.data
     a.mu = mu.ctypes.data if mu is not None else None
     a.freq = freq.ctypes.data if freq is not None else None

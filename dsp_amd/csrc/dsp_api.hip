@@ -317,7 +317,7 @@ int dsp_sync_tiles_dev(dsp_ctx *c, const dsp_sync_args *a)
     memset(&P, 0, sizeof(P));
     P.x = a->x; P.lens = a->lens; P.scale = a->scale;
     P.B = (int)a->B; P.in_rows = (int)a->in_rows; P.len_all = (int)a->N; P.sps = sps;
-    P.alpha = a->alpha; P.mu0 = a->mu0; P.half_len = a->variant == 2 ? 0 : a->interp_half_len;
+    P.alpha = a->alpha; P.mu0 = a->mu0; P.mu0_per = a->variant == DSP_GARDNER2 ? a->mu0_per : nullptr; P.half_len = a->variant == 2 ? 0 : a->interp_half_len;
     if (fll) dsp_fll_gains(a->Bn, a->y, &P.kp, &P.ki);
     P.i0 = a->i0; P.fll_in = a->fll_state_in; P.fll_out = a->fll_state_out;
     P.rec = a->variant == 2 ? nullptr : a->rec;
@@ -1221,9 +1221,18 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
                                         d_starts.as<int64_t>()));
     }
 
+    // ---- initial timing phase per window (strobe energy), unless the caller fixes mu0 ------------
+    DevBuf d_mu0;
+    if (a->acquire) {
+        HIP_TRY(d_mu0.alloc((size_t)S * 8));
+        HIP_TRY(launch_seg_phase(d_tiles.p, (int)rows, d_lens.as<int>(), S, sps, DSP_ACQUIRE_SYMBOLS,
+                                 d_mu0.as<double>(), st));
+    }
+
     // ---- the batched recurrence over the windows -------------------------------------------
     dsp_sync_args sa;
     memset(&sa, 0, sizeof(sa));
+    sa.mu0_per = d_mu0.as<double>();
     sa.x = d_tiles.p; sa.dtype = DSP_C64; sa.variant = DSP_GARDNER2; sa.B = S; sa.N = Nw; sa.in_rows = rows;
     sa.lens = d_lens.as<int32_t>(); sa.scale = d_scale; sa.sps = sps; sa.alpha = a->alpha; sa.mu0 = a->mu0; sa.do_fll = 1;
     sa.Bn = a->Bn; sa.y = a->y; sa.mu = a->mu ? d_mu.p : nullptr; sa.pos = d_pos.p; sa.dec = d_dec.as<uint8_t>(); sa.freq = a->freq ? d_freq.p : nullptr;

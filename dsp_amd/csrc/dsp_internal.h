@@ -26,6 +26,7 @@ struct SyncParams {
     // Gardner
     double alpha;             // gardner2: alpha; ted: delta_mu
     double mu0;
+    const double *mu0_per;    // [B] initial mu per burst (gardner2 variant), or NULL -> mu0
     int half_len;             // 0 = linear interpolation
     // FLL
     double kp, ki;
@@ -129,6 +130,8 @@ struct SegParams {
 };
 hipError_t launch_seg_windows(int S, int64_t n_total, int64_t seg_len, int64_t lead, int64_t tail,
                               int64_t *starts, int *lens, int *own_lo, int *own_hi, hipStream_t s);
+hipError_t launch_seg_phase(const void *tiles, int rows, const int *lens, int S, int sps, int n_sym, double *mu0,
+                            hipStream_t s);
 hipError_t launch_seg_stitch(const SegParams &P, int overlap_vote, hipStream_t s);
 hipError_t launch_seg_gather(const SegParams &P, uint8_t *dec_out, float *mu_out, float *freq_out,
                              int64_t capacity, hipStream_t s);

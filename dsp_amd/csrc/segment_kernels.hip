@@ -154,6 +154,59 @@ __global__ __launch_bounds__(1024) void seg_offsets_k(SegParams P)
     }
 }
 
+// Initial timing phase of every window (segment-parallel mode).  A window's timing loop starts cold;
+// started half a symbol away from the true timing it sits on the unstable zero of the Gardner
+// S-curve and may hang there for thousands of symbols (observed: one window in 16 384 still unlocked
+// after a 4096-symbol warm-up).  So each window starts at the sampling phase p in [0, sps) whose
+// strobes x[p + k sps], k < n_sym, carry the most energy -- the spectral line of |x|^2 at the symbol
+// rate (Oerder-Meyr) read on the sample grid, at most half a sample from the lock point.  Lane =
+// window over the tiled filter output; sums in float64, in k order (the oracle adds in the same order).
+__global__ __launch_bounds__(64) void seg_phase_k(const float2 *__restrict__ tiles, int rows,
+                                                  const int *__restrict__ lens, int S, int sps, int n_sym,
+                                                  double *__restrict__ mu0)
+{
+    const int lane = threadIdx.x, tile = blockIdx.x, w = tile * 64 + lane;
+    if (w >= S) return;
+    const int len = lens[w];
+    const int ns = n_sym < len / sps ? n_sym : len / sps;
+    const float2 *base = tiles + (size_t)tile * rows * 64 + lane;
+    double best = -1.0;
+    int arg = 0;
+    if (sps <= 8) {
+        // one pass, 4 symbols x sps rows loaded before they are added (the adds stay in k order)
+        double acc[8];
+#pragma unroll
+        for (int p = 0; p < 8; p++) acc[p] = 0.0;
+        for (int k0 = 0; k0 < ns; k0 += 4) {
+            float2 v[4][8];
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+                for (int p = 0; p < 8; p++)
+                    v[kk][p] = (p < sps && k0 + kk < ns) ? base[(size_t)((k0 + kk) * sps + p) * 64] : float2{0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+                for (int p = 0; p < 8; p++)
+                    if (p < sps && k0 + kk < ns)
+                        acc[p] += (double)v[kk][p].x * (double)v[kk][p].x + (double)v[kk][p].y * (double)v[kk][p].y;
+        }
+#pragma unroll
+        for (int p = 0; p < 8; p++)
+            if (p < sps && acc[p] > best) { best = acc[p]; arg = p; }
+    } else {
+        for (int p = 0; p < sps; p++) {
+            double acc = 0.0;
+            for (int k = 0; k < ns; k++) {
+                const float2 v = base[(size_t)(k * sps + p) * 64];
+                acc += (double)v.x * (double)v.x + (double)v.y * (double)v.y;
+            }
+            if (acc > best) { best = acc; arg = p; }
+        }
+    }
+    mu0[w] = (double)arg;
+}
+
 // 64 windows x 64 rows per workgroup through LDS so that both sides are contiguous
 __global__ __launch_bounds__(256) void seg_gather_k(SegParams P, uint8_t *__restrict__ dec_out,
                                                     float *__restrict__ mu_out, float *__restrict__ freq_out,
@@ -232,6 +285,14 @@ hipError_t launch_seg_windows(int S, int64_t n_total, int64_t seg_len, int64_t l
 {
     hipLaunchKernelGGL(seg_windows_k, dim3((S + 255) / 256), dim3(256), 0, s, S, n_total, seg_len, lead, tail,
                        starts, lens, own_lo, own_hi);
+    return hipGetLastError();
+}
+
+hipError_t launch_seg_phase(const void *tiles, int rows, const int *lens, int S, int sps, int n_sym, double *mu0,
+                            hipStream_t s)
+{
+    hipLaunchKernelGGL(seg_phase_k, dim3((S + 63) / 64), dim3(64), 0, s, (const float2 *)tiles, rows, lens, S, sps,
+                       n_sym, mu0);
     return hipGetLastError();
 }
 

@@ -399,12 +399,12 @@ __device__ __forceinline__ void tile_init(Tile<IN> &tl, const SyncParams &P, uns
 }
 
 __device__ __forceinline__ void timing_init(TimingConst &tc, dspm::GState &gs, const SyncParams &P,
-                                            int variant, int len, bool lane_ok)
+                                            int variant, int len, bool lane_ok, int b)
 {
     tc.len = len; tc.sps = P.sps; tc.spsd = (double)P.sps; tc.lend = (double)len; tc.alpha = P.alpha;
     tc.halfd = variant == DSP_VARIANT_TED ? tc.spsd / 2.0 : (double)(P.sps / 2);
     tc.n_symbols = 0;
-    gs.mu = variant == DSP_VARIANT_GARDNER2 ? P.mu0 : 0.0;
+    gs.mu = variant == DSP_VARIANT_GARDNER2 ? ((P.mu0_per && lane_ok) ? P.mu0_per[b] : P.mu0) : 0.0;
     gs.k = variant == DSP_VARIANT_GARDNER2 ? P.sps : 0;
     gs.active = lane_ok && len > 0;
     if (variant == DSP_VARIANT_TED) {
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(64) void sync_kernel(SyncParams P)
 
     TimingConst tc;
     dspm::GState gs;
-    timing_init(tc, gs, P, VARIANT, len, lane_ok);
+    timing_init(tc, gs, P, VARIANT, len, lane_ok, b);
     double freq = 0.0, integ = 0.0, i0 = 0.0;
     if (FLL && lane_ok) {
         if (P.fll_in) { freq = P.fll_in[2 * b]; integ = P.fll_in[2 * b + 1]; }
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(128) void sync_split_kernel(SyncParams P)
         if (ring) tl.prologue(sps, T, P.C);
         TimingConst tc;
         dspm::GState gs;
-        timing_init(tc, gs, P, VARIANT, len, lane_ok);
+        timing_init(tc, gs, P, VARIANT, len, lane_ok, b);
         OC *o_rec = (OC *)P.rec; OS *o_terr = (OS *)P.terr; OS *o_mu = (OS *)P.mu; OS *o_pos = (OS *)P.pos;
         int n_rec = 0;
         if (VARIANT == DSP_VARIANT_GARDNER2) {

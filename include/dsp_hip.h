@@ -170,6 +170,7 @@ typedef struct dsp_sync_args {
     int32_t *status;        /* [B] or NULL; bit0 = capacity reached                  */
     void *pos;              /* tiles or NULL: sample position k+mu of recovered symbol r+1 in row r
                                (gardner2.py:95; float32 / float64 like mu)              */
+    const double *mu0_per;  /* [B] or NULL: mu_initial per burst (DSP_GARDNER2), overrides mu0 */
 } dsp_sync_args;
 
 typedef struct dsp_fir_args {
@@ -316,7 +317,13 @@ typedef struct dsp_capture_args {
     int64_t capacity;
     int64_t *n_symbols;
     int32_t *seg_info;
+    int32_t acquire;        /* 1: every window starts its timing loop at the sampling phase (0..sps-1)
+                               whose strobes carry the most energy over its first DSP_ACQUIRE_SYMBOLS
+                               symbols (a cold start half a symbol off can hang on the Gardner S-curve's
+                               unstable zero for longer than any warm-up); 0: every window starts at mu0 */
+    int32_t reserved;
 } dsp_capture_args;
+#define DSP_ACQUIRE_SYMBOLS 256
 int dsp_sync_capture_segmented(dsp_ctx *ctx, const dsp_capture_args *args);
 int dsp_sync_capture_segmented_dev(dsp_ctx *ctx, const dsp_capture_args *args);
 int64_t dsp_capture_segments(int64_t n_samples, int64_t seg_len);   /* S = ceil(n / seg_len) */

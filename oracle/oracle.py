@@ -248,10 +248,29 @@ def _positions(start, mu, n, sps):
     return p
 
 
+def acquire_phase(w, sps, n_sym=256):
+    """Initial timing phase of a window (include/dsp_hip.h dsp_capture_args.acquire): the p in
+    [0, sps) whose strobes w[p + k sps], k < n_sym, carry the most energy; float64 sums in k order,
+    the first of equal maxima."""
+    ns = min(n_sym, len(w) // sps)
+    re = w.real.astype(np.float64)
+    im = w.imag.astype(np.float64)
+    best, arg = -1.0, 0
+    for p in range(sps):
+        acc = 0.0
+        for k in range(ns):
+            i = k * sps + p
+            acc += float(re[i] * re[i] + im[i] * im[i])
+        if acc > best:
+            best, arg = acc, p
+    return float(arg)
+
+
 def sync_capture_segmented(x, sps=4, alpha=0.007, mu0=0.0, Bn=0.003, y=1.0, seg_len=65536, warmup=2048,
-                           vote=None, scale=1.0):
+                           vote=None, scale=1.0, acquire=True):
     """x: the whole capture, complex64, already matched-filtered; scale: factor applied to the
-    samples in float64 (1/std of the whole filtered stream when the device filters)."""
+    samples in float64 (1/std of the whole filtered stream when the device filters); acquire: start
+    every window at acquire_phase(window) instead of mu0."""
     x = np.ascontiguousarray(x, dtype=np.complex64)
     n = x.size
     S = (n + seg_len - 1) // seg_len
@@ -261,7 +280,8 @@ def sync_capture_segmented(x, sps=4, alpha=0.007, mu0=0.0, Bn=0.003, y=1.0, seg_
     for s in range(S):
         st = max(0, s * seg_len - lead)
         en = n if s == S - 1 else min(n, (s + 1) * seg_len + tail)
-        o = sync_chain_c64(x[st:en], sps=sps, alpha=alpha, mu0=mu0, Bn=Bn, y=y, scale=scale)
+        m0 = acquire_phase(x[st:en], sps) if acquire else mu0
+        o = sync_chain_c64(x[st:en], sps=sps, alpha=alpha, mu0=m0, Bn=Bn, y=y, scale=scale)
         pos = _positions(float(st), o["mu"], o["n"], sps)
         wins.append((o, pos))
     dec, mu, freq, info = [], [], [], np.zeros((S, 4), np.int32)

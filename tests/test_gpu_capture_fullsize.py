@@ -1,0 +1,61 @@
+"""BASELINE config 5 at full size: ONE int16 capture of 2^30 samples through the segment-parallel
+receiver.  The sequential oracle would need minutes for this, so the checks are the
+size-independent properties the domain offers: the symbol count of a drifting clock, decisions equal
+to the transmitted symbols (up to ONE global QPSK rotation and a few symbol slips) at the start,
+three interior places and the very end of the stitched stream, every segment's share accounted
+for, and idempotence of a second run.  Small captures are compared with the oracle bit for bit in
+tests/test_segmented.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEED = 20251114
+TURN = np.array([1, 3, 0, 2], np.uint8)       # quadrant index after a +90 degree turn
+
+
+def _best_alignment(dec, centre, span=24):
+    """Best match of a run of decisions against the transmitted symbols around index `centre`:
+    -> (match rate, symbol offset, rotation)."""
+    from dsp_amd.synth import stream_symbols
+    n = dec.size
+    tx = stream_symbols(SEED, centre - span, n + 2 * span)
+    best = (0.0, 0, 0)
+    d = dec.copy()
+    for rot in range(4):
+        for off in range(2 * span + 1):
+            r = float(np.mean(d == tx[off:off + n]))
+            if r > best[0]:
+                best = (r, off - span, rot)
+        d = TURN[d]
+    return best
+
+
+def test_capture_2p30(ctx):
+    from dsp_amd.pipeline import CapturePipeline
+    n, sps, tau0, drift = 1 << 30, 4, 0.3, 2.0e-8
+    pipe = CapturePipeline(ctx, n, sps, seg_len=65536, warmup=4096)
+    try:
+        pipe.generate(SEED, tau0=tau0, drift=drift)
+        nsym = pipe.run()
+        assert abs(nsym - int(round(n * (1.0 + drift) / sps))) <= 4
+        assert pipe.S == n // 65536
+        info = pipe.info.copy()
+        # seg_info rows (first kept row, end row, rotation, rows produced): every window contributed a
+        # non-empty share inside what it produced, and the shares add up to the stitched stream
+        assert (info[:, 1] > info[:, 0]).all() and (info[:, 1] <= info[:, 3]).all() and (info[:, 0] >= 0).all()
+        assert int((info[:, 1].astype(np.int64) - info[:, 0]).sum()) == nsym
+        run = 8192
+        rots = []
+        for lo in (64, nsym // 4, nsym // 2 + 12345, 3 * (nsym // 4) + 777, nsym - run - 64):
+            dec = pipe.fetch("dec", lo, lo + run)
+            rate, off, rot = _best_alignment(dec, lo)
+            assert rate > 0.999, (lo, rate, off, rot)
+            assert abs(off) <= 8, (lo, off)                 # the drift moves the count by ~5 symbols end to end
+            rots.append(rot)
+        assert len(set(rots)) == 1, rots                    # ONE rotation ambiguity for the whole stream
+        d0 = pipe.fetch("dec", nsym // 2, nsym // 2 + (1 << 20))
+        assert pipe.run() == nsym
+        assert np.array_equal(pipe.fetch("dec", nsym // 2, nsym // 2 + (1 << 20)), d0)
+    finally:
+        pipe.close()
