@@ -217,6 +217,16 @@ __global__ __launch_bounds__(256) void seg_gather_k(SegParams P, uint8_t *__rest
     __shared__ float tf[64][65];
     const int tile = blockIdx.y, r0 = blockIdx.x * 64;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    {
+        // rows no window of this tile keeps (the warm-up rows, mostly): nothing to read or write
+        const int sw = tile * 64 + lane;
+        int lo = sw < P.S ? P.j0[sw] : 0x7fffffff, hi = sw < P.S ? P.j1[sw] : 0;
+        for (int d = 32; d >= 1; d >>= 1) {
+            const int ol = __shfl_xor(lo, d), oh = __shfl_xor(hi, d);
+            lo = ol < lo ? ol : lo; hi = oh > hi ? oh : hi;
+        }
+        if (r0 + 64 <= lo || r0 >= hi) return;          // uniform over the workgroup
+    }
     for (int i = 0; i < 16; i++) {
         const int rr = w * 16 + i, row = r0 + rr;
         if (row < P.out_rows) {
