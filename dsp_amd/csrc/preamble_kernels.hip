@@ -18,12 +18,87 @@ namespace {
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef double d2v __attribute__((ext_vector_type(2)));
 
+// Workgroup = DC_OUT consecutive sample positions i (all sps phases interleaved: phase = i % sps,
+// k = i / sps), thread = DC_PER of them spaced 256 apart.  D[i] = x[i + sps] * conj(x[i]) -- the
+// differential product of EVERY phase at once, since d_phase[k] = D[phase + k sps] -- is formed once per
+// sample from coalesced loads and kept in LDS; conv[phase][k] = sum_j D[i + j sps] conj(d_pre[j]) / std
+// is then a strided FIR over LDS with the exact two-pass np.std of the same L values.  The sums run
+// in j order (as the reference's np.sum / the previous thread-per-output kernel did).
+constexpr int DC_PER = 4, DC_OUT = 256 * DC_PER;
+
 template <typename IN>
 __global__ __launch_bounds__(256) void diff_corr_kernel(const IN *__restrict__ x, int64_t n, int sps,
                                                         const d2v *__restrict__ dpre, int L,
                                                         f2v *__restrict__ conv, int64_t kstride)
 {
-    extern __shared__ d2v pre_s[];                    // conj(d_pre)
+    extern __shared__ d2v smem_dc[];
+    d2v *pre_s = smem_dc;                             // [L] conj(d_pre)
+    d2v *D = smem_dc + L;                             // [DC_OUT + (L - 1) * sps]
+    const int64_t i0 = blockIdx.x * (int64_t)DC_OUT;
+    const int nD = DC_OUT + (L - 1) * sps;
+    for (int j = threadIdx.x; j < L; j += 256) pre_s[j] = d2v{dpre[j].x, -dpre[j].y};
+    for (int e = threadIdx.x; e < nD; e += 256) {
+        const int64_t i = i0 + e;
+        d2v d = {0.0, 0.0};
+        if (i + sps < n) {
+            const IN va = x[i], vb = x[i + sps];
+            const double ar = (double)va.x, ai = (double)va.y, br = (double)vb.x, bi = (double)vb.y;
+            d = d2v{br * ar + bi * ai, bi * ar - br * ai};            // b * conj(a)
+        }
+        D[e] = d;
+    }
+    __syncthreads();
+    double cr[DC_PER], ci[DC_PER], mr[DC_PER], mi[DC_PER], m2[DC_PER];
+#pragma unroll
+    for (int o = 0; o < DC_PER; o++) { cr[o] = ci[o] = mr[o] = mi[o] = m2[o] = 0.0; }
+    const int t = threadIdx.x;
+    for (int j = 0; j < L; j++) {
+        const d2v p = pre_s[j];
+#pragma unroll
+        for (int o = 0; o < DC_PER; o++) {
+            const d2v d = D[t + 256 * o + j * sps];
+            cr[o] += d.x * p.x - d.y * p.y;
+            ci[o] += d.x * p.y + d.y * p.x;
+            mr[o] += d.x; mi[o] += d.y;
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < DC_PER; o++) { mr[o] /= (double)L; mi[o] /= (double)L; }
+    for (int j = 0; j < L; j++) {
+#pragma unroll
+        for (int o = 0; o < DC_PER; o++) {
+            const d2v d = D[t + 256 * o + j * sps];
+            const double dr = d.x - mr[o], di = d.y - mi[o];
+            m2[o] += dr * dr + di * di;
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < DC_PER; o++) {
+        const int64_t i = i0 + t + 256 * o;
+        const int phase = (int)(i % sps);
+        const int64_t k = i / sps;
+        if (k >= kstride) continue;
+        // symbols of this phase: x[phase::sps] has ns entries, d has ns - 1
+        const int64_t ns = n > phase ? (n - phase + sps - 1) / sps : 0;
+        const int64_t nd = ns - 1;
+        f2v out = {0.f, 0.f};
+        if (k + L <= nd) {
+            const double Y = sqrt(m2[o] / (double)L);
+            if (Y > 0.0) out = f2v{(float)(cr[o] / Y), (float)(ci[o] / Y)};
+        }
+        conv[(int64_t)phase * kstride + k] = out;
+    }
+}
+
+// Fallback for preambles whose differential window does not fit LDS ((L - 1) * sps > ~9000): one
+// thread per (phase, k) straight from global memory.
+template <typename IN>
+__global__ __launch_bounds__(256) void diff_corr_direct_kernel(const IN *__restrict__ x, int64_t n, int sps,
+                                                        const d2v *__restrict__ dpre, int L,
+                                                        f2v *__restrict__ conv, int64_t kstride)
+{
+    extern __shared__ d2v pre_direct[];
+    d2v *pre_s = pre_direct;                    // conj(d_pre)
     for (int j = threadIdx.x; j < L; j += 256) pre_s[j] = d2v{dpre[j].x, -dpre[j].y};
     __syncthreads();
     const int phase = blockIdx.y;
@@ -70,11 +145,33 @@ hipError_t launch_diff_corr(const void *x, int c128, int64_t n, int sps, const v
                             int64_t kstride, hipStream_t s)
 {
     if (kstride <= 0 || sps <= 0) return hipSuccess;
-    dim3 grid((unsigned)((kstride + 255) / 256), sps), block(256);
-    const size_t lds = (size_t)L * 16;
-    if (c128) hipLaunchKernelGGL(diff_corr_kernel<d2v>, grid, block, lds, s, (const d2v *)x, n, sps, (const d2v *)dpre, L,
-                                 (f2v *)conv, kstride);
-    else hipLaunchKernelGGL(diff_corr_kernel<f2v>, grid, block, lds, s, (const f2v *)x, n, sps, (const d2v *)dpre, L,
-                            (f2v *)conv, kstride);
+    const int64_t total = kstride * sps;                       // positions i = phase + k sps to cover
+    const int64_t nblk = (total + DC_OUT - 1) / DC_OUT;
+    if (nblk > 0x7fffffff) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(L + DC_OUT + (size_t)(L - 1) * sps) * 16;
+    if (lds > 144 * 1024) {                                    // long preamble: thread per (phase, k)
+        dim3 g2((unsigned)((kstride + 255) / 256), sps);
+        if (c128) hipLaunchKernelGGL(diff_corr_direct_kernel<d2v>, g2, dim3(256), (size_t)L * 16, s, (const d2v *)x, n, sps,
+                                     (const d2v *)dpre, L, (f2v *)conv, kstride);
+        else hipLaunchKernelGGL(diff_corr_direct_kernel<f2v>, g2, dim3(256), (size_t)L * 16, s, (const f2v *)x, n, sps,
+                                (const d2v *)dpre, L, (f2v *)conv, kstride);
+        return hipGetLastError();
+    }
+    dim3 grid((unsigned)nblk), block(256);
+    if (c128) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)diff_corr_kernel<d2v>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(diff_corr_kernel<d2v>, grid, block, lds, s, (const d2v *)x, n, sps, (const d2v *)dpre, L,
+                           (f2v *)conv, kstride);
+    } else {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)diff_corr_kernel<f2v>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(diff_corr_kernel<f2v>, grid, block, lds, s, (const f2v *)x, n, sps, (const d2v *)dpre, L,
+                           (f2v *)conv, kstride);
+    }
     return hipGetLastError();
 }

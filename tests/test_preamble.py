@@ -123,3 +123,23 @@ def test_generation_reproduces_reference(tmp_path):
     save_as_pcm_float32_iq(samples, path)
     back = dsp_amd.read_iq_float32(path)
     assert np.array_equal(back, samples.astype(np.complex64))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_pre,sps,nsym", [(300, 32, 340), (130, 3, 400), (2, 1, 50)])
+def test_diff_corr_shapes(oracle, n_pre, sps, nsym):
+    """Preambles long enough to leave the LDS-staged kernel for the direct one ((L-1)*sps > ~9000),
+    an odd sps with a ragged tail, and the shortest preamble at one sample per symbol: all against
+    the restated loop."""
+    import dsp_amd
+    rng = np.random.default_rng(n_pre)
+    n = nsym * sps + (sps // 2)
+    pre = np.exp(1j * np.pi / 2 * rng.integers(0, 4, n_pre))
+    x = 0.5 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    x[7 * sps + 1:7 * sps + 1 + n_pre * sps:sps] += pre * np.exp(0.3j)
+    got = dsp_amd.diff_corr(x, pre, sps)
+    _, _, want, _, _ = oracle.find_preamble_offset(x, pre, sps)
+    assert len(got) == sps
+    for p in range(sps):
+        assert got[p].shape == want[p].shape
+        assert np.abs(got[p] - want[p]).max() <= 2e-6 * max(1.0, np.abs(want[p]).max())
