@@ -167,3 +167,32 @@ def test_receiver_records_f_rel():
         assert np.array_equal(peaks, gw[f"w_peaks_{tag}"])
         assert np.abs(pr.f_rel - gc[f"w_frel_{tag}"]).max() < 1e-10
         assert len(found) == int(gw[f"w_nfound_{tag}"])
+
+
+@pytest.mark.gpu
+def test_front_end_argument_errors():
+    """Bad arguments come back as exceptions with a message, never as a fault on the device."""
+    import dsp_amd
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(4000) + 1j * rng.standard_normal(4000))
+    pre = np.exp(1j * np.pi / 2 * rng.integers(0, 4, 32))
+    h = dsp_amd.rrc_filter(4, 10, 0.35)
+    with pytest.raises(dsp_amd.DspError):
+        dsp_amd.rx_bursts(x, [-1], 400, pre, h)                       # cut starts before the signal
+    with pytest.raises(dsp_amd.DspError):
+        dsp_amd.rx_bursts(x, [3700], 400, pre, h)                     # ... ends after it
+    with pytest.raises(dsp_amd.DspError):
+        dsp_amd.rx_bursts(x, [0], 40, pre, h)                         # packet shorter than the filter
+    with pytest.raises(dsp_amd.DspError):
+        dsp_amd.rx_bursts(x, [0], 100, pre, h)                        # ... than the preamble
+    with pytest.raises(dsp_amd.DspError):
+        dsp_amd.rx_bursts(x, [0], 400, pre, h, cfo_method=7)
+    out = dsp_amd.rx_bursts(x, [], 400, pre, h)                       # no bursts: empty result
+    assert out["n_out"].size == 0 and out["f_rel"].size == 0
+    assert dsp_amd.derotate(np.zeros(0, np.complex128), 0.1).size == 0
+    assert dsp_amd.estimate_initial_frequency_batch(np.zeros((3, 0), np.complex128), 5).tolist() == [0.0, 0.0, 0.0]
+    assert dsp_amd.preamble_cfo(x, pre, 4, []).shape == (0, 3)
+    with pytest.raises(dsp_amd.DspError):
+        dsp_amd.preamble_cfo(x, pre, 4, [4000 - 31 * 4])              # last preamble symbol one sample out
+    o = dsp_amd.fll_slicer_batch(np.zeros((0, 5), np.complex128), 0.01, 1, "8psk")
+    assert o["sig"].shape == (0, 5)
