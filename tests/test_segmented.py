@@ -65,6 +65,34 @@ def test_oracle_segmented_vs_sequential(oracle, stream):
     assert best_rotation_match(seg["dec"][500:n], q[500:n]) > 0.999
 
 
+@pytest.fixture(scope="module")
+def stream_half(oracle):
+    """True timing half a symbol from mu = 0: the worst cold start of a Gardner loop."""
+    q, x, h = make_stream(40000, seed=9, tau=2.05)
+    y = oracle.filter_samples(x, h).astype(np.complex64)
+    return q, x, h, y
+
+
+def test_oracle_segmented_half_symbol_offset(oracle, stream_half):
+    """Windows started cold at mu = 0 hang on the detector's unstable zero and the stitched stream is
+    useless; started at the strobe-energy phase (acquire, the default) they lock at once and agree
+    with a sequential loop started at the same lock point to < 1e-3 symbol."""
+    q, x, h, y = stream_half
+    assert oracle.acquire_phase(y[:4096], SPS) == 2.0
+    cold = oracle.sync_capture_segmented(y, SPS, 0.007, 0.0, 0.003, 1.0, seg_len=16384, warmup=4096, acquire=False)
+    n = min(cold["n"], q.size)
+    assert best_rotation_match(cold["dec"][12000:n], q[12000:n]) < 0.6
+    seg = oracle.sync_capture_segmented(y, SPS, 0.007, 0.0, 0.003, 1.0, seg_len=16384, warmup=4096)
+    n = min(seg["n"], q.size)
+    assert best_rotation_match(seg["dec"][2000:n], q[2000:n]) > 0.999
+    rec, err, mu = oracle.gardner_timing_recovery(y, SPS, 0.007, 2.0)
+    assert abs(seg["n"] - len(rec)) <= 1
+    mu_seq = np.concatenate(([2.0], mu))
+    m = min(len(mu_seq), len(seg["mu"]))
+    dm = np.abs(seg["mu"][2000:m] - mu_seq[2000:m])
+    assert np.max(dm) / SPS < 1e-3, np.max(dm)
+
+
 def test_oracle_segmented_single_segment_is_sequential(oracle, stream):
     q, x, h, y = stream
     seg = oracle.sync_capture_segmented(y[:20000], SPS, 0.007, 0.0, 0.003, 1.0, seg_len=32768, warmup=512)
@@ -84,6 +112,25 @@ def test_gpu_segmented_matches_oracle(oracle, stream, ctx):
         assert np.array_equal(got["dec"], ref["dec"])                        # bit-exact decisions
         assert np.max(np.abs(got["mu"] - ref["mu"])) < 1e-6
         assert np.max(np.abs(got["freq"] - ref["freq"])) < 1e-9              # 1e-4 rad/sample >> this
+
+
+@pytest.mark.gpu
+def test_gpu_segmented_half_symbol_offset(oracle, stream_half, ctx):
+    """Per-window phase acquisition on the device: same start phases, shares, rotations and decisions
+    as the restatement, with and without it."""
+    import dsp_amd
+    q, x, h, y = stream_half
+    for acq in (True, False):
+        ref = oracle.sync_capture_segmented(y, SPS, 0.007, 0.0, 0.003, 1.0, seg_len=16384, warmup=2048, acquire=acq)
+        got = dsp_amd.sync_capture_segmented(y, SPS, 0.007, 0.0, 0.003, 1, seg_len=16384, warmup=2048, acquire=acq,
+                                             ctx=ctx)
+        assert got["n"] == ref["n"]
+        assert np.array_equal(got["seg_info"], ref["seg_info"])
+        assert np.array_equal(got["dec"], ref["dec"])
+        assert np.max(np.abs(got["mu"] - ref["mu"])) < 1e-6
+    n = min(got["n"], q.size)
+    assert best_rotation_match(dsp_amd.sync_capture_segmented(y, SPS, 0.007, 0.0, 0.003, 1, seg_len=16384, warmup=2048,
+                                                              ctx=ctx)["dec"][2000:n], q[2000:n]) > 0.999
 
 
 @pytest.mark.gpu
