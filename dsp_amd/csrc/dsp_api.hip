@@ -338,26 +338,34 @@ int dsp_sync_tiles_dev(dsp_ctx *c, const dsp_sync_args *a)
     const int elem = a->dtype == DSP_C128 ? 16 : 8;
     const int ntiles = (P.B + 63) / 64;
     const bool can_split = fll && a->variant != 2 && P.half_len == 0;
-    const bool split = can_split && c->split != 0;
     const int n_store_t = count_nonnull({P.rec, P.terr, P.mu, P.pos});
     const int n_store_f = count_nonnull({P.sig, P.freq, P.ef, P.dec});
-    const int n_store = split ? n_store_t : n_store_t + n_store_f;
     int per_cu = (ntiles + 255) / 256;
     if (per_cu < 1) per_cu = 1;
     size_t budget = ((size_t)160 * 1024 / per_cu) & ~(size_t)2047;   // LDS is allocated in coarse blocks
     if (budget > 64 * 1024) budget = 64 * 1024;
-    int R = c->ring_rows;
-    if (R == 0) {
-        R = (sps > 8 || P.half_len > 2) ? 128 : 64;
-        // prefer a smaller ring when that lets every tile be resident at once
-        while (R > 32 && (size_t)R * 64 * elem + (split ? 2200 : 0) > budget &&
-               sync_plan(elem, sps, P.half_len, a->variant, n_store, R / 2).use_ring)
-            R /= 2;
+    const size_t queue_min = (size_t)2 * 64 * 17 + 16;               // hand-off queue with TQ = 1
+    size_t lds = 0;
+    bool split = can_split && c->split != 0;
+    for (;;) {
+        const int n_store = split ? n_store_t : n_store_t + n_store_f;
+        int R = c->ring_rows;
+        if (R == 0) {
+            R = (sps > 8 || P.half_len > 2) ? 128 : 64;
+            // prefer a smaller ring when that lets every tile be resident at once
+            while (R > 32 && (size_t)R * 64 * elem + (split ? 2200 : 0) > budget &&
+                   sync_plan(elem, sps, P.half_len, a->variant, n_store, R / 2).use_ring)
+                R /= 2;
+        }
+        if ((size_t)R * 64 * elem > 64 * 1024) R = 64 * 1024 / (64 * elem);
+        SyncPlan pl = sync_plan(elem, sps, P.half_len, a->variant, n_store, R);
+        // ring and queue share one 64 KiB allocation: a ring that leaves no room for the smallest queue
+        // (wide samples with many samples per symbol) runs as one wave per tile instead
+        if (split && (size_t)pl.lds_bytes + queue_min > 64 * 1024) { split = false; continue; }
+        P.use_ring = pl.use_ring; P.ring_rows = pl.ring_rows; P.T = pl.T; P.C = pl.C; P.nwait = pl.nwait;
+        lds = (size_t)pl.lds_bytes;
+        break;
     }
-    if ((size_t)R * 64 * elem > 64 * 1024) R = 64 * 1024 / (64 * elem);
-    SyncPlan pl = sync_plan(elem, sps, P.half_len, a->variant, n_store, R);
-    P.use_ring = pl.use_ring; P.ring_rows = pl.ring_rows; P.T = pl.T; P.C = pl.C; P.nwait = pl.nwait;
-    size_t lds = (size_t)pl.lds_bytes;
     P.TQ = 0;
     if (split) {
         // queue block: as many symbols as the double buffer can hold inside the budget

@@ -78,10 +78,15 @@ __device__ __forceinline__ void st_cplx(f2v *p, double re, double im, bool keep 
     v.y = keep ? v.y : 0.0f;
     asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(v) : "memory");
 }
+// A store of more than 64 bits reads its data VGPRs for a few cycles after it issues: a VALU write to
+// them needs 2 wait states after the store on gfx940+ (1 before).  The compiler's hazard recogniser
+// pads its own stores but cannot see inside inline asm, so the pad is part of the asm text here
+// (without it the low dword of the real part came out overwritten in lanes 12-15 of every 16).
+#define DSP_WIDE_STORE_PAD "\n\ts_nop 1"
 __device__ __forceinline__ void st_cplx(d2v *p, double re, double im, bool keep = true)
 {
     d2v v = {keep ? re : 0.0, keep ? im : 0.0};
-    asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off" DSP_WIDE_STORE_PAD :: "v"(p), "v"(v) : "memory");
 }
 
 // stores through a wave-uniform base (SGPR pair) + 32-bit lane offset: no 64-bit VALU address math
@@ -99,7 +104,7 @@ __device__ __forceinline__ void sst(const void *base, unsigned voff, f2v v)
 }
 __device__ __forceinline__ void sst(const void *base, unsigned voff, d2v v)
 {
-    asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(voff), "v"(v), "s"(base) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2" DSP_WIDE_STORE_PAD :: "v"(voff), "v"(v), "s"(base) : "memory");
 }
 __device__ __forceinline__ void sst_b8(const void *base, unsigned voff, unsigned v)
 {
