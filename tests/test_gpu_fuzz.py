@@ -88,3 +88,186 @@ def test_fuzz_chain(ctx, oracle, trial):
             if outs == "all":
                 assert np.array_equal(got["err"][b, :nm], err.astype(rdt))
                 assert np.max(np.abs(got["sig"][b, :H] - sl[:H])) < (1e-6 if c64 else 1e-9) * max(1.0, np.abs(sl[:H]).max())
+
+
+@pytest.mark.parametrize("trial", range(32))
+def test_fuzz_fir(ctx, oracle, trial):
+    """Matched filter + /np.std over random tap counts (LDS-tiled kernel and the direct form for long
+    filters), burst counts, ragged lengths, 'same' and cropped-full alignment, both sample types."""
+    import dsp_amd
+    rng = np.random.default_rng(5000 + trial)
+    M = int(rng.choice([1, 2, 5, 16, 41, 41, 64, 81, 87, 88, 89, 120, 301]))
+    B = int(rng.choice([1, 2, 63, 64, 65, 150]))
+    N = int(M + rng.choice([0, 1, 7, 96, 97, 500, 1500]))
+    c64 = bool(rng.integers(0, 2))
+    normalize = bool(rng.integers(0, 2))
+    start = int(rng.choice([-1, -1, M // 2, 0, M - 1]))
+    h = rng.standard_normal(M)
+    lens = None
+    X = rng.standard_normal((B, N)) + 1j * rng.standard_normal((B, N))
+    if rng.integers(0, 2):
+        lens = rng.integers(M, N + 1, B).astype(np.int32)
+        for b in range(B):
+            X[b, lens[b]:] = 0
+    if c64:
+        X = X.astype(np.complex64)
+    y, std = dsp_amd.fir_batch(X, h, normalize=normalize, start=start, lens=lens, want_std=True, ctx=ctx)
+    assert y.dtype == X.dtype
+    st = (M - 1) // 2 if start < 0 else start
+    for b in sorted(set([0, B // 2, B - 1, min(B - 1, 13), min(B - 1, 62)])):
+        L = N if lens is None else int(lens[b])
+        x = X[b, :L].astype(np.complex128)
+        full = np.convolve(x, h)                         # 'same' == full[(M-1)//2 :][:L] (np.convolve, odd or even M)
+        ref = full[st:st + L]
+        s = np.sqrt(np.mean(np.abs(ref - ref.mean()) ** 2))
+        assert abs(std[b] - s) <= 1e-12 * max(s, 1e-300), (b, std[b], s)
+        if normalize:
+            ref = ref * (1.0 / s)
+        tol = (2e-7 if c64 else 1e-13) * max(1.0, np.abs(ref).max())
+        assert np.max(np.abs(y[b, :L] - ref)) <= tol, (b, np.max(np.abs(y[b, :L] - ref)), tol)
+        assert not y[b, L:].any()
+
+
+@pytest.mark.parametrize("trial", range(16))
+def test_fuzz_rx_chain(ctx, oracle, trial):
+    """Raw bursts (int16 pairs, complex64, complex128) through filter + /std + Gardner + FLL in one call,
+    against the oracle run stage by stage; more bursts than 12 so every lane group of a tile is used."""
+    import dsp_amd
+    rng = np.random.default_rng(7000 + trial)
+    kind = int(rng.integers(0, 3))                           # 0 int16, 1 complex64, 2 complex128
+    sps = int(rng.choice([2, 4, 4, 8]))
+    B = int(rng.choice([3, 20, 64, 70]))
+    nsym = int(rng.choice([40, 150, 400]))
+    N = nsym * sps
+    h = dsp_amd.rrc_filter(sps, 10, 0.35)
+    if N < h.size:
+        N = h.size + 3
+    sym = np.exp(1j * (np.pi / 4 + np.pi / 2 * rng.integers(0, 4, (B, N // sps + 1))))
+    up = np.zeros((B, N), complex)
+    up[:, ::sps] = sym[:, :len(range(0, N, sps))]
+    tx = np.stack([np.convolve(u, h, "same") for u in up])
+    tx = tx * np.exp(1j * (2 * np.pi * rng.uniform(-3e-4, 3e-4, (B, 1)) * np.arange(N) + rng.uniform(0, 6, (B, 1))))
+    tx = tx + 0.03 * (rng.standard_normal((B, N)) + 1j * rng.standard_normal((B, N)))
+    lens = rng.integers(h.size, N + 1, B).astype(np.int32) if rng.integers(0, 2) else None
+    if kind == 0:
+        raw = np.zeros((B, 2 * N), np.int16)
+        raw[:, 0::2] = np.clip(np.rint(tx.real * 8000), -32768, 32767)
+        raw[:, 1::2] = np.clip(np.rint(tx.imag * 8000), -32768, 32767)
+        if lens is not None:
+            for b in range(B):
+                raw[b, 2 * lens[b]:] = 0
+        X = raw
+        peak = np.float32(np.sqrt(np.max(raw[:, 0::2].astype(np.float64) ** 2 + raw[:, 1::2].astype(np.float64) ** 2)))
+        iq = (raw[:, 0::2].astype(np.float32) + 1j * raw[:, 1::2].astype(np.float32)).astype(np.complex64)
+        xin = (iq / peak).astype(np.complex64)                # read_iq_int16 over the whole block
+    else:
+        X = tx.astype(np.complex64 if kind == 1 else np.complex128)
+        if lens is not None:
+            for b in range(B):
+                X[b, lens[b]:] = 0
+        xin = X
+    got = dsp_amd.rx_chain_batch(X, h, sps, 0.007, 0.0, 0.03, 1, lens=lens, outputs=("rec", "mu", "sig", "freq", "dec"),
+                                 ctx=ctx)
+    f32 = kind != 2
+    for b in sorted(set([0, B - 1, min(B - 1, 14), min(B - 1, 45), min(B - 1, 63)])):
+        L = N if lens is None else int(lens[b])
+        y = oracle.convolve_same(xin[b, :L].astype(np.complex128), h)
+        s = oracle.np_std(y)
+        assert abs(got["std"][b] - s) <= 1e-12 * s
+        if f32:
+            y = y.astype(np.complex64).astype(np.complex128)  # the filter output is held as complex64 ...
+        y = y * (1.0 / s)                                     # ... and 1/std applied in float64 by the loop kernel
+        rec, err, mu = oracle.gardner_timing_recovery(y, sps, 0.007, 0.0)
+        n = len(rec)
+        assert got["n_out"][b] == n
+        if f32:
+            # the device filter rounds its float64 sums to complex64 once; the oracle's sums differ in the
+            # last bits before that rounding, so trajectories agree to float32 resolution, not bit for bit
+            assert np.max(np.abs(got["mu"][b, :n - 1] - mu)) < 2e-4
+            assert np.max(np.abs(got["rec"][b, :n] - rec)) < 2e-5 * max(1.0, np.abs(rec).max())
+        else:
+            assert np.max(np.abs(got["mu"][b, :n - 1] - mu)) < 1e-9
+            assert np.max(np.abs(got["rec"][b, :n] - rec)) < 1e-11 * max(1.0, np.abs(rec).max())
+        sl, cf, fr, ef = oracle.fll_func(rec, 0.03, 1)
+        assert np.max(np.abs(got["freq"][b, :n] - fr)) < (1e-6 if f32 else 1e-10)
+        q = oracle.quadrants(sl)
+        agree = np.mean(got["dec"][b, :n] == q)
+        assert agree == 1.0 if not f32 else agree > 0.995, (b, agree)
+
+
+@pytest.mark.parametrize("trial", range(12))
+def test_fuzz_segmented(ctx, oracle, trial):
+    """Segment-parallel mode over random capture lengths, segment lengths, warm-ups, samples per symbol
+    and timing offsets (with and without the phase acquisition): the device equals the restatement."""
+    import dsp_amd
+    rng = np.random.default_rng(9000 + trial)
+    sps = int(rng.choice([2, 4, 4, 8]))
+    nsym = int(rng.choice([900, 3000, 7001]))
+    seg_len = int(rng.choice([256, 1024, 4096, 65536])) * sps
+    warm = int(rng.choice([0, 64, 300, 1000]))
+    acquire = bool(rng.integers(0, 2))
+    h = dsp_amd.rrc_filter(sps, 10, 0.35)
+    q = rng.integers(0, 4, nsym)
+    sym = ((1 - 2 * (q & 1)) + 1j * (1 - 2 * (q >> 1))) / np.sqrt(2)
+    up = np.zeros(nsym * sps + int(rng.integers(0, sps)), complex)
+    up[:nsym * sps:sps] = sym
+    tx = np.convolve(up, h, "same")
+    t = np.arange(tx.size, dtype=float)
+    d = rng.uniform(0, sps) + 1e-6 * t
+    x = (np.interp(t - d, t, tx.real) + 1j * np.interp(t - d, t, tx.imag)) * np.exp(1j * (2 * np.pi * 1e-4 * t + 0.3))
+    x = x + 0.05 * (rng.standard_normal(x.size) + 1j * rng.standard_normal(x.size))
+    y = oracle.filter_samples(x, h).astype(np.complex64)
+    ref = oracle.sync_capture_segmented(y, sps, 0.007, 0.0, 0.003, 1.0, seg_len=seg_len, warmup=warm, acquire=acquire)
+    got = dsp_amd.sync_capture_segmented(y, sps, 0.007, 0.0, 0.003, 1, seg_len=seg_len, warmup=warm, acquire=acquire,
+                                         ctx=ctx)
+    assert got["n"] == ref["n"]
+    assert np.array_equal(got["seg_info"], ref["seg_info"])
+    assert np.array_equal(got["dec"], ref["dec"])
+    assert np.max(np.abs(got["mu"] - ref["mu"]), initial=0) < 1e-6
+    assert np.max(np.abs(got["freq"] - ref["freq"]), initial=0) < 1e-9
+
+
+@pytest.mark.parametrize("trial", range(10))
+def test_fuzz_front_end(ctx, oracle, trial):
+    """diff_corr, the preamble CFO estimators, the fourth-power estimator, derotation and the table
+    slicers on random shapes against the restated loops."""
+    import dsp_amd
+    rng = np.random.default_rng(11000 + trial)
+    sps = int(rng.choice([1, 2, 3, 4, 7]))
+    n_pre = int(rng.choice([2, 3, 17, 64, 200]))
+    n = int((n_pre + rng.integers(2, 120)) * sps + rng.integers(0, sps))
+    pre = np.exp(1j * np.pi / 2 * rng.integers(0, 4, n_pre))
+    x = 0.4 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    o = int(rng.integers(0, n - (n_pre - 1) * sps))
+    m = len(x[o:o + n_pre * sps:sps])
+    x[o:o + n_pre * sps:sps] += pre[:m] * np.exp(1j * (0.02 * np.arange(m) + 1))
+    if rng.integers(0, 2):
+        x = x.astype(np.complex64)
+    got = dsp_amd.diff_corr(x, pre, sps, ctx=ctx)
+    _, _, want, _, _ = oracle.find_preamble_offset(x, pre, sps)
+    for p in range(sps):
+        assert got[p].shape == want[p].shape
+        assert np.abs(got[p] - want[p]).max(initial=0) <= 3e-6 * max(1.0, np.abs(want[p]).max(initial=0))
+    offs = np.sort(rng.integers(0, n - (n_pre - 1) * sps, 5)).astype(np.int64)
+    f = dsp_amd.preamble_cfo(x, pre, sps, offs, ctx=ctx)
+    for k, off in enumerate(offs):
+        w = oracle.preamble_cfo(np.asarray(x[off::sps][:n_pre], dtype=np.complex128), pre, sps)
+        ok = np.isfinite(w)                                  # two-symbol preambles leave the line fit undefined
+        assert np.abs(f[k][ok] - w[ok]).max(initial=0) < 1e-11
+    rows = x[:(n // 5) * 5].reshape(5, -1)
+    ns = int(rng.integers(0, rows.shape[1] + 3))
+    ff = dsp_amd.estimate_initial_frequency_batch(rows, ns, ctx=ctx)
+    want_f = np.array([oracle.estimate_initial_frequency(np.asarray(r, dtype=np.complex128), ns) for r in rows])
+    assert np.abs(ff - want_f).max() < 1e-11
+    d = dsp_amd.derotate(x, 1.3e-3, offset=int(o), ctx=ctx)
+    assert np.abs(d - oracle.derotate(x, 1.3e-3, int(o))).max() < 1e-12 * max(1.0, np.abs(x).max())
+    for c in ("8psk", "16apsk"):
+        s = oracle.constellation_points(c)[rng.integers(0, 8, 90)] * np.exp(1j * 1e-3 * np.arange(90))
+        s = s + 0.02 * (rng.standard_normal(90) + 1j * rng.standard_normal(90))
+        B = int(rng.choice([1, 14, 66]))
+        S = np.tile(s, (B, 1))
+        out = dsp_amd.fll_slicer_batch(S, 0.02, 1, c, ctx=ctx)
+        sl, cf, fr, ef, dec = oracle.fll_func_constellation(s, 0.02, 1, c)
+        for b in (0, B - 1, min(B - 1, 13)):
+            assert np.abs(out["sig"][b] - sl).max() < 1e-9 and np.array_equal(out["dec"][b], dec)
+            assert np.abs(out["freq"][b] - fr).max() < 1e-12
