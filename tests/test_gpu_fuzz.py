@@ -271,3 +271,49 @@ def test_fuzz_front_end(ctx, oracle, trial):
         for b in (0, B - 1, min(B - 1, 13)):
             assert np.abs(out["sig"][b] - sl).max() < 1e-9 and np.array_equal(out["dec"][b], dec)
             assert np.abs(out["freq"][b] - fr).max() < 1e-12
+
+
+@pytest.mark.parametrize("trial", range(6))
+def test_fuzz_lagrange_and_continuation(ctx, oracle, trial):
+    """The Lagrange-interpolator timing loop on several bursts per tile (every lane group), ragged, both
+    sample types; and fll_batch continued from a random split point with i0 / state on 70 ragged streams."""
+    import dsp_amd
+    from test_gpu_lagrange import gardner2_lagrange_restated
+    rng = np.random.default_rng(13000 + trial)
+    sps = int(rng.choice([2, 4]))
+    half = int(rng.choice([1, 2, 4]))
+    B, N = int(rng.choice([14, 66])), 320
+    X = np.stack([_burst(rng, N, sps, 1) for _ in range(B)])
+    lens = rng.integers(6 * sps, N + 1, B).astype(np.int32)
+    for b in range(B):
+        X[b, lens[b]:] = 0
+    c64 = bool(rng.integers(0, 2))
+    Xd = X.astype(np.complex64) if c64 else X
+    g_rec, g_err, g_mu, n_out = dsp_amd.gardner_batch(Xd, sps, 0.02, 0.0, lens=lens, interp_half_len=half, ctx=ctx)
+    for b in (0, 13, B - 1):
+        rec, err, mu = gardner2_lagrange_restated(oracle, Xd[b, :lens[b]].astype(np.complex128), sps, 0.02, half)
+        n = int(n_out[b])
+        assert n == len(rec)
+        tol = 1e-6 if c64 else 1e-11
+        assert np.max(np.abs(g_mu[b, :n - 1] - mu), initial=0) < tol
+        assert np.max(np.abs(g_rec[b, :n] - rec)) < tol * max(1.0, np.abs(rec).max())
+    # FLL continuation
+    Bf, M = 70, 600
+    S = np.stack([_burst(rng, M, 1, 1) for _ in range(Bf)])
+    ml = rng.integers(2, M + 1, Bf).astype(np.int32)
+    for b in range(Bf):
+        S[b, ml[b]:] = 0
+    cut = int(rng.integers(1, M - 1))
+    l1 = np.minimum(ml, cut).astype(np.int32)
+    l2 = (ml - l1).astype(np.int32)
+    full = dsp_amd.fll_batch(S, 0.02, 1, lens=ml, ctx=ctx)
+    a = dsp_amd.fll_batch(S[:, :cut], 0.02, 1, lens=l1, want_state=True, ctx=ctx)
+    c = dsp_amd.fll_batch(np.ascontiguousarray(S[:, cut:]), 0.02, 1, lens=l2, i0=np.full(Bf, float(cut)), state=a[5],
+                          want_state=True, ctx=ctx)
+    for b in (0, 12, 15, 63, 64, 69):
+        if ml[b] > cut:
+            assert np.array_equal(np.concatenate([a[2][b, :cut], c[2][b, :ml[b] - cut]]), full[2][b, :ml[b]])
+            assert np.array_equal(np.concatenate([a[4][b, :cut], c[4][b, :ml[b] - cut]]), full[4][b, :ml[b]])
+        o = oracle.fll_func(S[b, :ml[b]], 0.02, 1)
+        assert np.max(np.abs(full[2][b, :ml[b]] - o[2])) < FREQ_TOL
+        assert np.array_equal(full[4][b, :ml[b]], oracle.quadrants(o[0]))
