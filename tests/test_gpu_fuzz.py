@@ -317,3 +317,28 @@ def test_fuzz_lagrange_and_continuation(ctx, oracle, trial):
         o = oracle.fll_func(S[b, :ml[b]], 0.02, 1)
         assert np.max(np.abs(full[2][b, :ml[b]] - o[2])) < FREQ_TOL
         assert np.array_equal(full[4][b, :ml[b]], oracle.quadrants(o[0]))
+
+
+def test_long_burst(ctx, oracle):
+    """Two bursts of 2^21 samples (524 288 symbols each, far beyond the benchmark's 2048): the
+    recurrences, the DMA ring and the output indexing over half a million rows, against the oracle."""
+    import dsp_amd
+    rng = np.random.default_rng(21)
+    sps, N = 4, 1 << 21
+    X = np.zeros((2, N), np.complex64)
+    for b in range(2):
+        sym = np.exp(1j * (np.pi / 4 + np.pi / 2 * rng.integers(0, 4, N // sps)))
+        x = np.repeat(sym, sps) * np.exp(1j * (2 * np.pi * 2e-5 * np.arange(N) + b))
+        k = np.arange(N) % sps
+        x = x * (0.6 + 0.4 * np.cos(2 * np.pi * (k + 0.3 * b) / sps))          # a symbol-rate envelope to lock on
+        X[b] = (x + 0.05 * (rng.standard_normal(N) + 1j * rng.standard_normal(N))).astype(np.complex64)
+    lens = np.array([N, N - 12345], np.int32)
+    X[1, lens[1]:] = 0
+    got = dsp_amd.sync_chain_batch(X, sps, 0.007, 0.0, 1e-4, 1, lens=lens, outputs=("dec", "mu", "freq"), ctx=ctx)
+    for b in range(2):
+        o = oracle.sync_chain_c64(X[b, :lens[b]], sps=sps, alpha=0.007, Bn=1e-4, y=1.0)
+        n = o["n"]
+        assert got["n_out"][b] == n and n > 520000
+        assert np.array_equal(got["mu"][b, :n - 1], o["mu"].astype(np.float32))
+        assert np.array_equal(got["dec"][b, :n], o["dec"])
+        assert np.max(np.abs(got["freq"][b, :n] - o["freq"])) < 1e-9
