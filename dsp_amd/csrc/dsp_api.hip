@@ -342,8 +342,10 @@ int dsp_sync_tiles_dev(dsp_ctx *c, const dsp_sync_args *a)
     const int n_store_f = count_nonnull({P.sig, P.freq, P.ef, P.dec});
     int per_cu = (ntiles + 255) / 256;
     if (per_cu < 1) per_cu = 1;
-    size_t budget = ((size_t)160 * 1024 / per_cu) & ~(size_t)2047;   // LDS is allocated in coarse blocks
-    if (budget > 64 * 1024) budget = 64 * 1024;
+    const size_t budget_all = ((size_t)160 * 1024 / per_cu) & ~(size_t)2047;   // LDS is allocated in coarse blocks
+    // the input ring must stay below 64 KiB (the LDS-DMA base register M0 addresses no more); the
+    // two-wave kernel's hand-off queue may lie above it when the workgroup may have more LDS
+    const size_t budget = budget_all > 64 * 1024 ? 64 * 1024 : budget_all;
     const size_t queue_min = (size_t)2 * 64 * 17 + 16;               // hand-off queue with TQ = 1
     size_t lds = 0;
     bool split = can_split && c->split != 0;
@@ -359,9 +361,8 @@ int dsp_sync_tiles_dev(dsp_ctx *c, const dsp_sync_args *a)
         }
         if ((size_t)R * 64 * elem > 64 * 1024) R = 64 * 1024 / (64 * elem);
         SyncPlan pl = sync_plan(elem, sps, P.half_len, a->variant, n_store, R);
-        // ring and queue share one 64 KiB allocation: a ring that leaves no room for the smallest queue
-        // (wide samples with many samples per symbol) runs as one wave per tile instead
-        if (split && (size_t)pl.lds_bytes + queue_min > 64 * 1024) { split = false; continue; }
+        // a ring that leaves no room for the smallest queue runs as one wave per tile instead
+        if (split && (size_t)pl.lds_bytes + queue_min > budget_all) { split = false; continue; }
         P.use_ring = pl.use_ring; P.ring_rows = pl.ring_rows; P.T = pl.T; P.C = pl.C; P.nwait = pl.nwait;
         lds = (size_t)pl.lds_bytes;
         break;
@@ -369,20 +370,21 @@ int dsp_sync_tiles_dev(dsp_ctx *c, const dsp_sync_args *a)
     P.TQ = 0;
     if (split) {
         // queue block: as many symbols as the double buffer can hold inside the budget
+        const size_t room = lds + queue_min > budget ? budget_all : budget;
         int TQ = c->queue_block;
         if (TQ == 0) {
             TQ = 1;
             for (int d = 16; d >= 1; d--)
-                if (lds + (size_t)2 * d * 64 * 17 + 16 <= budget) { TQ = d; break; }
+                if (lds + (size_t)2 * d * 64 * 17 + 16 <= room) { TQ = d; break; }
         }
-        while (TQ > 1 && lds + (size_t)2 * TQ * 64 * 17 + 16 > 64 * 1024) TQ--;
+        while (TQ > 1 && lds + (size_t)2 * TQ * 64 * 17 + 16 > room) TQ--;
         P.TQ = TQ;
         P.prio_period = c->prio_period;
         lds += (size_t)2 * TQ * 64 * 17 + 16;
     }
     if (c->lds_pad >= 0) lds += (size_t)c->lds_pad;
     else if (budget > lds) lds = budget;
-    if (lds > 64 * 1024) lds = 64 * 1024;
+    if (lds > budget_all) return fail(DSP_E_ARG, "sync: %zu bytes of LDS needed, %zu available per workgroup", lds, budget_all);
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(launch_sync(P, a->dtype == DSP_C128, a->variant, fll, lds, c->stream));
     return DSP_OK;

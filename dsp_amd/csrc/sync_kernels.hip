@@ -818,13 +818,15 @@ static hipError_t launch_in(const SyncParams &P, int variant, bool fll, size_t l
 {
     if (P.TQ > 0) {        // two waves per tile (timing wave + FLL wave)
         int ntiles = (P.B + 63) / 64;
-        if (variant == DSP_VARIANT_GARDNER2) {
-            if (P.scale) hipLaunchKernelGGL((sync_split_kernel<IN, DSP_VARIANT_GARDNER2, true>), dim3(ntiles), dim3(128), lds, s, P);
-            else hipLaunchKernelGGL((sync_split_kernel<IN, DSP_VARIANT_GARDNER2, false>), dim3(ntiles), dim3(128), lds, s, P);
-        } else {
-            if (P.scale) hipLaunchKernelGGL((sync_split_kernel<IN, DSP_VARIANT_TED, true>), dim3(ntiles), dim3(128), lds, s, P);
-            else hipLaunchKernelGGL((sync_split_kernel<IN, DSP_VARIANT_TED, false>), dim3(ntiles), dim3(128), lds, s, P);
+        void (*k)(SyncParams) =
+            variant == DSP_VARIANT_GARDNER2
+                ? (P.scale ? sync_split_kernel<IN, DSP_VARIANT_GARDNER2, true> : sync_split_kernel<IN, DSP_VARIANT_GARDNER2, false>)
+                : (P.scale ? sync_split_kernel<IN, DSP_VARIANT_TED, true> : sync_split_kernel<IN, DSP_VARIANT_TED, false>);
+        if (lds > 64 * 1024) {     // ring below 64 KiB, queue above it: has to be asked for
+            hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
         }
+        hipLaunchKernelGGL(k, dim3(ntiles), dim3(128), lds, s, P);
         return hipGetLastError();
     }
     switch (variant) {
