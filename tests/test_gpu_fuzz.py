@@ -342,3 +342,29 @@ def test_long_burst(ctx, oracle):
         assert np.array_equal(got["mu"][b, :n - 1], o["mu"].astype(np.float32))
         assert np.array_equal(got["dec"][b, :n], o["dec"])
         assert np.max(np.abs(got["freq"][b, :n] - o["freq"])) < 1e-9
+
+
+@pytest.mark.parametrize("trial", range(12))
+def test_fuzz_loaders_and_resampler(ctx, oracle, trial):
+    """read_iq_int16 on random word counts (odd tails, extreme values, all zeros) bit for bit, and
+    lagrange_resample at random positions including nodes and both ends."""
+    import dsp_amd
+    rng = np.random.default_rng(15000 + trial)
+    nw = int(rng.choice([2, 3, 4, 5, 127, 128, 129, 4097, 100003]))
+    raw = rng.integers(-32768, 32768, nw).astype(np.int16)
+    if trial % 4 == 1:
+        raw[:] = 0
+    if trial % 4 == 2:
+        raw[rng.integers(0, nw)] = -32768
+    for norm in (True, False):
+        got = dsp_amd.read_iq_int16_words(raw, norm, ctx=ctx)
+        want = oracle.read_iq_int16_words(raw, norm)
+        assert got.dtype == np.complex64 and np.array_equal(got, want)
+    n = int(rng.choice([1, 2, 9, 300, 5000]))
+    half = int(rng.choice([1, 2, 3, 4, 8]))
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    pos = np.concatenate([rng.uniform(-2, n + 2, 400), np.arange(min(n, 20), dtype=float), [0.0, n - 1.0, n - 1 + 1e-13]])
+    got = dsp_amd.lagrange_resample(x, pos, half, ctx=ctx)
+    want = oracle.lagrange_resample(x, pos, half)
+    assert got.dtype == x.dtype
+    assert np.max(np.abs(got - want)) < 1e-12 * max(1.0, np.abs(want).max())
