@@ -368,3 +368,40 @@ def test_fuzz_loaders_and_resampler(ctx, oracle, trial):
     want = oracle.lagrange_resample(x, pos, half)
     assert got.dtype == x.dtype
     assert np.max(np.abs(got - want)) < 1e-12 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("method", [1, 2, 3])
+def test_rx_bursts_many(ctx, oracle, method):
+    """dsp_rx_bursts on 40 bursts cut from one signal (more than a lane group; partly filled tile):
+    every burst against the oracle chain -- estimator, derotation, filter + /std, Gardner, FLL."""
+    import dsp_amd
+    rng = np.random.default_rng(17000 + method)
+    sps, n_pre, n_sym, gap, nb = 4, 48, 260, 37, 40
+    h = dsp_amd.rrc_filter(sps, 10, 0.35)
+    pre = np.exp(1j * (np.pi / 4 + np.pi / 2 * rng.integers(0, 4, n_pre)))
+    parts, offs, pos = [np.zeros(gap * sps, complex)], [], gap * sps
+    for b in range(nb):
+        sym = np.concatenate([pre, np.exp(1j * (np.pi / 4 + np.pi / 2 * rng.integers(0, 4, n_sym - n_pre)))])
+        up = np.zeros(n_sym * sps, complex)
+        up[::sps] = sym
+        parts += [up, np.zeros(gap * sps, complex)]
+        offs.append(pos)
+        pos += (n_sym + gap) * sps
+    x = np.convolve(np.concatenate(parts), h, "same")
+    t = np.arange(x.size)
+    x = x * np.exp(1j * 2 * np.pi * 3e-4 * t) + 0.03 * (rng.standard_normal(x.size) + 1j * rng.standard_normal(x.size))
+    n_pkt = n_sym * sps
+    out = dsp_amd.rx_bursts(x, offs, n_pkt, pre, h, sps, 0.007, 0.0, 0.03, 1, cfo_method=method,
+                            outputs=("sig", "dec", "mu"), ctx=ctx)
+    for b, o in enumerate(offs):
+        cut = x[o:o + n_pkt]
+        f = oracle.preamble_cfo(cut[::sps][:n_pre], pre, sps)[method - 1]
+        assert abs(out["f_rel"][b] - f) < 1e-12
+        y = oracle.filter_samples(oracle.derotate(cut, f, o), h)
+        rec, err, mu = oracle.gardner_timing_recovery(y, sps, 0.007, 0.0)
+        s, _, _, _ = oracle.fll_func(rec, 0.03, 1)
+        n = len(s)
+        assert int(out["n_out"][b]) == n
+        assert np.max(np.abs(out["mu"][b, :n - 1] - mu)) < 1e-8
+        assert np.max(np.abs(out["sig"][b, :n] - s)) < 1e-7
+        assert np.array_equal(out["dec"][b, :n], oracle.quadrants(s))
