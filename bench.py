@@ -82,8 +82,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--bursts", type=int, default=65536, help="bursts per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-lean", action="store_true",
-                    help="skip the informational decisions-only launches (profiling: keeps every launch alike)")
+    ap.add_argument("--lean", action="store_true",
+                    help="also time the launch with decisions as the only output (informational; off by "
+                         "default so that every launch of a profiled run is the measured one)")
     ap.add_argument("--ring-rows", type=int, default=0)
     ap.add_argument("--lds-pad", type=int, default=-1)
     ap.add_argument("--split", type=int, default=-1, help="-1 auto, 0 one wave per tile, 1 two")
@@ -176,7 +177,7 @@ def main():
     # ---- informational: the same launch with decisions as the only output (A_lean = 8.25 B/sample,
     #      SURVEY.md 8d); not part of `value`
     lean_ms = None
-    if rank == 0 and not args.no_lean:
+    if rank == 0 and args.lean:
         a = pipe._sync_args
         saved = {k: getattr(a, k) for k in ("rec", "err", "mu", "sig", "freq", "ef")}
         for k in saved:
