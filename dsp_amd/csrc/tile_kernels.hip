@@ -77,7 +77,12 @@ __global__ __launch_bounds__(256) void stream_copy_k(const f4v *__restrict__ a, 
 hipError_t launch_stream_copy(const void *src, void *dst, size_t bytes, hipStream_t s)
 {
     if (bytes < 16) return hipSuccess;
-    hipLaunchKernelGGL(stream_copy_k, dim3(32768), dim3(256), 0, s, (const f4v *)src, (f4v *)dst, bytes / 16);
+    // two float4 per thread: the best of the shapes tools/ubench/copy_bw.hip tries on this hardware
+    // (5.3 TB/s read + write; 32768 workgroups looping longer reach 4.9, hipMemcpyDtoD 4.7)
+    size_t wgs = (bytes / 16 + 511) / 512;
+    if (wgs > 131072) wgs = 131072;
+    if (wgs < 1) wgs = 1;
+    hipLaunchKernelGGL(stream_copy_k, dim3((unsigned)wgs), dim3(256), 0, s, (const f4v *)src, (f4v *)dst, bytes / 16);
     return hipGetLastError();
 }
 
