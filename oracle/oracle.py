@@ -119,11 +119,15 @@ def gardner_timing_recovery(signal, sps, alpha=0.007, mu_initial=0.0):
     if x.size == 0:
         raise IndexError("index 0 is out of bounds for axis 0 with size 0")
     cap = x.size // max(int(sps), 1) + 8
-    rec = np.empty(cap, np.complex128)
-    err = np.empty(cap, np.float64)
-    mu = np.empty(cap, np.float64)
-    n = lib().orc_gardner2(_p(x), x.size, int(sps), float(alpha), float(mu_initial),
-                           _p(rec), _p(err), _p(mu), cap)
+    for attempt in range(2):                # a loop that slips backwards can emit more than len/sps symbols;
+        rec = np.empty(cap, np.complex128)  # one that never ends (gardner2.py can) still fails after the retry
+        err = np.empty(cap, np.float64)
+        mu = np.empty(cap, np.float64)
+        n = lib().orc_gardner2(_p(x), x.size, int(sps), float(alpha), float(mu_initial),
+                               _p(rec), _p(err), _p(mu), cap)
+        if n != -2:
+            break
+        cap *= 4
     if n < 0:
         raise RuntimeError(f"orc_gardner2 failed ({n})")
     return rec[:n].copy(), err[:n - 1].copy(), mu[:n - 1].copy()

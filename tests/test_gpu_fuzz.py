@@ -6,9 +6,12 @@ Gardner outputs must be bit-exact and the FLL frequency within 1e-12 inside its 
 import numpy as np
 import pytest
 
+import os
+
 pytestmark = pytest.mark.gpu
 
 FREQ_TOL = 1e-12
+SCALE = int(os.environ.get("DSP_FUZZ_SCALE", "1"))        # DSP_FUZZ_SCALE=10: ten times the trials (soak run)
 
 
 def _burst(rng, n, sps, kind):
@@ -26,7 +29,7 @@ def _burst(rng, n, sps, kind):
     return x + 0.05 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
 
 
-@pytest.mark.parametrize("trial", range(64))
+@pytest.mark.parametrize("trial", range(64 * SCALE))
 def test_fuzz_chain(ctx, oracle, trial):
     import dsp_amd
     rng = np.random.default_rng(1000 + trial)
@@ -59,6 +62,15 @@ def test_fuzz_chain(ctx, oracle, trial):
     try:
         got = dsp_amd.sync_chain_batch(X, sps, alpha, mu0, Bn, 1, variant=variant, lens=lens, scale=scale,
                                        outputs=outs, ctx=ctx)
+    except dsp_amd.DspError as e:
+        # gardner2.py's own loop does not end on some inputs (k -= sps undoes k += sps): the device reports
+        # the burst; the oracle must run out of room on the same burst
+        assert e.code == -3 and variant == 0, e
+        b = int(str(e).split("burst ")[1].split(":")[0])
+        x = X[b, :lens[b]].astype(np.complex128) * (scale[b] if scale is not None else 1.0)
+        with pytest.raises(RuntimeError):
+            oracle.gardner_timing_recovery(x, sps, alpha, mu0)
+        return
     finally:
         ctx.set_option("split", -1)
     kp = 4 * Bn / 1000 / 1.25
@@ -90,7 +102,7 @@ def test_fuzz_chain(ctx, oracle, trial):
                 assert np.max(np.abs(got["sig"][b, :H] - sl[:H])) < (1e-6 if c64 else 1e-9) * max(1.0, np.abs(sl[:H]).max())
 
 
-@pytest.mark.parametrize("trial", range(32))
+@pytest.mark.parametrize("trial", range(32 * SCALE))
 def test_fuzz_fir(ctx, oracle, trial):
     """Matched filter + /np.std over random tap counts (LDS-tiled kernel and the direct form for long
     filters), burst counts, ragged lengths, 'same' and cropped-full alignment, both sample types."""
@@ -121,6 +133,9 @@ def test_fuzz_fir(ctx, oracle, trial):
         ref = full[st:st + L]
         s = np.sqrt(np.mean(np.abs(ref - ref.mean()) ** 2))
         assert abs(std[b] - s) <= 1e-12 * max(s, 1e-300), (b, std[b], s)
+        if normalize and s == 0.0:                       # one-sample burst: numpy divides by zero as well
+            assert not np.isfinite(y[b, :L]).all()
+            continue
         if normalize:
             ref = ref * (1.0 / s)
         tol = (2e-7 if c64 else 1e-13) * max(1.0, np.abs(ref).max())
@@ -128,7 +143,7 @@ def test_fuzz_fir(ctx, oracle, trial):
         assert not y[b, L:].any()
 
 
-@pytest.mark.parametrize("trial", range(16))
+@pytest.mark.parametrize("trial", range(16 * SCALE))
 def test_fuzz_rx_chain(ctx, oracle, trial):
     """Raw bursts (int16 pairs, complex64, complex128) through filter + /std + Gardner + FLL in one call,
     against the oracle run stage by stage; more bursts than 12 so every lane group of a tile is used."""
@@ -195,7 +210,7 @@ def test_fuzz_rx_chain(ctx, oracle, trial):
         assert agree == 1.0 if not f32 else agree > 0.995, (b, agree)
 
 
-@pytest.mark.parametrize("trial", range(12))
+@pytest.mark.parametrize("trial", range(12 * SCALE))
 def test_fuzz_segmented(ctx, oracle, trial):
     """Segment-parallel mode over random capture lengths, segment lengths, warm-ups, samples per symbol
     and timing offsets (with and without the phase acquisition): the device equals the restatement."""
@@ -227,7 +242,7 @@ def test_fuzz_segmented(ctx, oracle, trial):
     assert np.max(np.abs(got["freq"] - ref["freq"]), initial=0) < 1e-9
 
 
-@pytest.mark.parametrize("trial", range(10))
+@pytest.mark.parametrize("trial", range(10 * SCALE))
 def test_fuzz_front_end(ctx, oracle, trial):
     """diff_corr, the preamble CFO estimators, the fourth-power estimator, derotation and the table
     slicers on random shapes against the restated loops."""
@@ -273,7 +288,7 @@ def test_fuzz_front_end(ctx, oracle, trial):
             assert np.abs(out["freq"][b] - fr).max() < 1e-12
 
 
-@pytest.mark.parametrize("trial", range(6))
+@pytest.mark.parametrize("trial", range(6 * SCALE))
 def test_fuzz_lagrange_and_continuation(ctx, oracle, trial):
     """The Lagrange-interpolator timing loop on several bursts per tile (every lane group), ragged, both
     sample types; and fll_batch continued from a random split point with i0 / state on 70 ragged streams."""
@@ -344,7 +359,7 @@ def test_long_burst(ctx, oracle):
         assert np.max(np.abs(got["freq"][b, :n] - o["freq"])) < 1e-9
 
 
-@pytest.mark.parametrize("trial", range(12))
+@pytest.mark.parametrize("trial", range(12 * SCALE))
 def test_fuzz_loaders_and_resampler(ctx, oracle, trial):
     """read_iq_int16 on random word counts (odd tails, extreme values, all zeros) bit for bit, and
     lagrange_resample at random positions including nodes and both ends."""
