@@ -143,3 +143,21 @@ def test_diff_corr_shapes(oracle, n_pre, sps, nsym):
     for p in range(sps):
         assert got[p].shape == want[p].shape
         assert np.abs(got[p] - want[p]).max() <= 2e-6 * max(1.0, np.abs(want[p]).max())
+
+
+@pytest.mark.gpu
+def test_demo_worker_script():
+    """tools/demo_worker.py = the reference's test_worker.py flow (interp=True): five noise-free packets
+    found half a sample apart on the doubled grid, every packet received and decided correctly."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("demo_worker", os.path.join(os.path.dirname(GOLDEN), "..", "tools",
+                                                                              "demo_worker.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    peaks, found, f_rel, best, quad = mod.main(True)
+    assert list(map(int, peaks)) == [240, 16480, 32720, 48960, 65200]
+    assert len(found) == 5 and all(len(f) == 2000 for f in found)
+    assert np.abs(f_rel).max() < 1e-4
+    assert quad > 0.97          # the loops acquire over the first symbols of a packet
+    peaks, found, f_rel, best, quad = mod.main(False)
+    assert list(map(int, peaks)) == [120, 8240, 16360, 24480, 32600]      # the peaks SURVEY.md 8c quotes
