@@ -332,7 +332,7 @@ def rx_chain_batch(x, taps, sps=4, alpha=0.007, mu_initial=0.0, Bn=0.03, y=1, *,
 
 
 def sync_capture_segmented(x, sps=4, alpha=0.007, mu_initial=0.0, Bn=0.003, y=1, *, taps=None,
-                           seg_len=65536, warmup=4096, normalize=True, want=("dec", "mu", "freq"),
+                           seg_len=32768, warmup=4096, normalize=True, want=("dec", "mu", "freq"),
                            acquire=True, ctx=None):
     """Segment-parallel Gardner + FLL + decisions over ONE long capture (no reference
     counterpart; north-star (c), include/dsp_hip.h dsp_sync_capture_segmented).

@@ -1221,7 +1221,12 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
         Q.stat_lo = d_lo.as<int>(); Q.stat_hi = d_hi.as<int>();
         Q.len_all = (int)Nw; Q.B = S; Q.h = a->h; Q.M = a->n_taps; Q.start = (a->n_taps - 1) / 2;
         Q.in_scale = in_scale; Q.dst = d_tiles.p; Q.rows = (int)rows; Q.stats = d_ws.as<double>();
+        // the warm-up rows of a window are rows its predecessor filters anyway: skip them here (every
+        // tile but the first) and copy them over afterwards
+        const bool share_lead = lead > 0 && lead <= seg && S > 64;
+        Q.skip_rows = share_lead ? (int)lead : 0;
         HIP_TRY(launch_fir_tile(Q, a->in_kind, st));
+        if (share_lead) HIP_TRY(launch_seg_lead_copy(d_tiles.p, (int)rows, d_starts.as<int64_t>(), S, (int)lead, st));
         HIP_TRY(launch_fir_stats_global(Q.stats, (int64_t)S * Q.nchunk, S, nullptr, d_inv.as<double>(),
                                         d_part.as<double>(), 1024, st));
         d_scale = d_inv.as<double>();

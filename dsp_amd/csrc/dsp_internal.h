@@ -87,6 +87,7 @@ struct FirParams {
     const double *scale;      // [B] factor applied to the outputs (1/std), or NULL
     double *stats;            // [B][nchunk][4] partial statistics, or NULL
     int nchunk, CH, W, stride;
+    int skip_rows;            // tiles > 0 skip the chunks that end at or before this output row (0 = none)
 };
 
 bool fir_plan(int in_kind, int M, int n_out, FirParams &P);
@@ -130,6 +131,7 @@ struct SegParams {
 };
 hipError_t launch_seg_windows(int S, int64_t n_total, int64_t seg_len, int64_t lead, int64_t tail,
                               int64_t *starts, int *lens, int *own_lo, int *own_hi, hipStream_t s);
+hipError_t launch_seg_lead_copy(void *tiles, int rows, const int64_t *starts, int S, int lead, hipStream_t s);
 hipError_t launch_seg_phase(const void *tiles, int rows, const int *lens, int S, int sps, int n_sym, double *mu0,
                             hipStream_t s);
 hipError_t launch_seg_stitch(const SegParams &P, int overlap_vote, hipStream_t s);

@@ -47,6 +47,14 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
 
     const int tile = blockIdx.y, chunk = blockIdx.x;
     const int n0 = chunk * CH;
+    if (tile > 0 && n0 + CH <= P.skip_rows) {           // rows another kernel fills (segment-parallel mode):
+        const int sb = tile * 64 + (int)threadIdx.x;    // leave empty statistics records behind
+        if (P.stats && threadIdx.x < 64 && sb < P.B) {
+            double *st = P.stats + ((size_t)sb * P.nchunk + chunk) * 4;
+            st[0] = 0.0; st[1] = 0.0; st[2] = 0.0; st[3] = 0.0;
+        }
+        return;
+    }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float isc = P.in_scale ? *P.in_scale : 1.0f;
 

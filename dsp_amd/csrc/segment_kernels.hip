@@ -154,6 +154,27 @@ __global__ __launch_bounds__(1024) void seg_offsets_k(SegParams P)
     }
 }
 
+// Warm-up rows of the windows from their predecessors (segment-parallel mode with the matched filter).
+// Row r < lead of window w holds stream sample starts[w] + r, which is row starts[w] + r - starts[w-1]
+// of window w - 1 -- one of its own (already filtered) rows when lead <= seg_len.  The filter therefore
+// skips those rows in every tile but the first and this copy fills them: the same values bit for bit
+// (a sample's filter sum does not depend on the window it is computed in), at a copy's cost instead of
+// the filter's.  Idle lanes of the last tile are cleared.  Grid: (lead / 4 rounded up, tiles - 1).
+__global__ __launch_bounds__(256) void seg_lead_copy_k(float2 *__restrict__ tiles, int rows,
+                                                       const int64_t *__restrict__ starts, int S, int lead)
+{
+    const int lane = threadIdx.x & 63, tile = blockIdx.y + 1;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= lead) return;
+    const int w = tile * 64 + lane;
+    float2 v = {0.f, 0.f};
+    if (w < S) {
+        const int64_t rs = starts[w] + r - starts[w - 1];
+        v = tiles[((size_t)((w - 1) >> 6) * rows + (size_t)rs) * 64 + ((w - 1) & 63)];
+    }
+    tiles[((size_t)tile * rows + r) * 64 + lane] = v;
+}
+
 // Initial timing phase of every window (segment-parallel mode).  A window's timing loop starts cold;
 // started half a symbol away from the true timing it sits on the unstable zero of the Gardner
 // S-curve and may hang there for thousands of symbols (observed: one window in 16 384 still unlocked
@@ -295,6 +316,15 @@ hipError_t launch_seg_windows(int S, int64_t n_total, int64_t seg_len, int64_t l
 {
     hipLaunchKernelGGL(seg_windows_k, dim3((S + 255) / 256), dim3(256), 0, s, S, n_total, seg_len, lead, tail,
                        starts, lens, own_lo, own_hi);
+    return hipGetLastError();
+}
+
+hipError_t launch_seg_lead_copy(void *tiles, int rows, const int64_t *starts, int S, int lead, hipStream_t s)
+{
+    const int ntiles = (S + 63) / 64;
+    if (ntiles < 2 || lead <= 0) return hipSuccess;
+    hipLaunchKernelGGL(seg_lead_copy_k, dim3((lead + 3) / 4, ntiles - 1), dim3(256), 0, s, (float2 *)tiles, rows, starts, S,
+                       lead);
     return hipGetLastError();
 }
 

@@ -164,7 +164,7 @@ class CapturePipeline:
     decisions (and mu / frequency per symbol) stay on the device until fetch()."""
 
     def __init__(self, ctx, n_samples, sps=4, span=10, rolloff=0.35, alpha=0.007, mu0=0.0, Bn=0.003,
-                 y=1.0, seg_len=65536, warmup=4096, int16=True, matched_filter=True, want_mu=True,
+                 y=1.0, seg_len=32768, warmup=4096, int16=True, matched_filter=True, want_mu=True,
                  want_freq=False, acquire=True):
         self.ctx, self.L = ctx, _lib.lib()
         self.n, self.sps = int(n_samples), int(sps)

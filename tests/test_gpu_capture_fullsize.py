@@ -31,15 +31,16 @@ def _best_alignment(dec, centre, span=24):
     return best
 
 
-def test_capture_2p30(ctx):
+@pytest.mark.parametrize("seg_len", [32768, 65536])
+def test_capture_2p30(ctx, seg_len):
     from dsp_amd.pipeline import CapturePipeline
     n, sps, tau0, drift = 1 << 30, 4, 0.3, 2.0e-8
-    pipe = CapturePipeline(ctx, n, sps, seg_len=65536, warmup=4096)
+    pipe = CapturePipeline(ctx, n, sps, seg_len=seg_len, warmup=4096)
     try:
         pipe.generate(SEED, tau0=tau0, drift=drift)
         nsym = pipe.run()
         assert abs(nsym - int(round(n * (1.0 + drift) / sps))) <= 4
-        assert pipe.S == n // 65536
+        assert pipe.S == n // seg_len
         info = pipe.info.copy()
         # seg_info rows (first kept row, end row, rotation, rows produced): every window contributed a
         # non-empty share inside what it produced, and the shares add up to the stitched stream

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Config 5 of BASELINE.json: one continuous int16 IQ capture, segment-parallel receiver.
 
-    python tools/bench_capture.py [log2_samples=28] [seg_len=65536] [warmup=4096]
+    python tools/bench_capture.py [log2_samples=28] [seg_len=32768] [warmup=4096]
 
 Generates the capture on the device, runs the whole segmented receiver (peak, RRC + std of the
 whole stream, windows, Gardner + FLL, stitching), checks the decisions against the transmitted
@@ -47,7 +47,7 @@ def check_decisions(pipe, n_sym, tau0, drift, sps, lo, count):
 
 def main():
     lg = int(sys.argv[1]) if len(sys.argv) > 1 else 28
-    seg_len = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+    seg_len = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
     warmup = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
     n, sps = 1 << lg, 4
     tau0, drift = 0.3, 2.0e-8
