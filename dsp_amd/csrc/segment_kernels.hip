@@ -159,20 +159,27 @@ __global__ __launch_bounds__(1024) void seg_offsets_k(SegParams P)
 // of window w - 1 -- one of its own (already filtered) rows when lead <= seg_len.  The filter therefore
 // skips those rows in every tile but the first and this copy fills them: the same values bit for bit
 // (a sample's filter sum does not depend on the window it is computed in), at a copy's cost instead of
-// the filter's.  Idle lanes of the last tile are cleared.  Grid: (lead / 4 rounded up, tiles - 1).
+// the filter's.  Idle lanes of the last tile are cleared.  Grid: (lead / 64 rounded up, tiles - 1).
 __global__ __launch_bounds__(256) void seg_lead_copy_k(float2 *__restrict__ tiles, int rows,
                                                        const int64_t *__restrict__ starts, int S, int lead)
 {
     const int lane = threadIdx.x & 63, tile = blockIdx.y + 1;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= lead) return;
     const int w = tile * 64 + lane;
-    float2 v = {0.f, 0.f};
-    if (w < S) {
-        const int64_t rs = starts[w] + r - starts[w - 1];
-        v = tiles[((size_t)((w - 1) >> 6) * rows + (size_t)rs) * 64 + ((w - 1) & 63)];
+    const int64_t shift = w < S ? starts[w] - starts[w - 1] : 0;
+    const float2 *src = tiles + (size_t)((w - 1) >> 6) * rows * 64 + ((w - 1) & 63);
+    float2 *dst = tiles + (size_t)tile * rows * 64 + lane;
+    const int r0 = blockIdx.x * 64 + (threadIdx.x >> 6);
+    float2 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {                      // 64 rows per workgroup, 16 loads in flight per lane
+        const int r = r0 + 4 * i;
+        v[i] = (w < S && r < lead) ? src[(size_t)(shift + r) * 64] : float2{0.f, 0.f};
     }
-    tiles[((size_t)tile * rows + r) * 64 + lane] = v;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int r = r0 + 4 * i;
+        if (r < lead) dst[(size_t)r * 64] = v[i];
+    }
 }
 
 // Initial timing phase of every window (segment-parallel mode).  A window's timing loop starts cold;
@@ -323,7 +330,7 @@ hipError_t launch_seg_lead_copy(void *tiles, int rows, const int64_t *starts, in
 {
     const int ntiles = (S + 63) / 64;
     if (ntiles < 2 || lead <= 0) return hipSuccess;
-    hipLaunchKernelGGL(seg_lead_copy_k, dim3((lead + 3) / 4, ntiles - 1), dim3(256), 0, s, (float2 *)tiles, rows, starts, S,
+    hipLaunchKernelGGL(seg_lead_copy_k, dim3((lead + 63) / 64, ntiles - 1), dim3(256), 0, s, (float2 *)tiles, rows, starts, S,
                        lead);
     return hipGetLastError();
 }
