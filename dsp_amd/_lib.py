@@ -139,6 +139,7 @@ def _declare(L):
     L.dsp_synth_bursts_dev.argtypes = [vp, C.c_uint64, i64, i64, ci, ci, vp, ci, dbl, vp]
     L.dsp_synth_stream_dev.argtypes = [vp, C.c_uint64, i64, ci, vp, ci, dbl, dbl, dbl, dbl, ci, dbl, vp]
     L.dsp_diff_corr.argtypes = [vp, vp, ci, i64, vp, ci, ci, vp, i64]
+    L.dsp_trim.argtypes = [vp]
     L.dsp_fll_slicer.argtypes = [vp, vp, ci, i64, i64, i64, vp, ci, vp, ci, dbl, dbl, vp, vp, vp, vp, i64, vp]
     L.dsp_cfo_preamble.argtypes = [vp, vp, ci, i64, vp, i64, ci, vp, ci, vp]
     L.dsp_cfo_fourth_power.argtypes = [vp, vp, ci, i64, i64, i64, vp, i64, vp]
@@ -159,7 +160,7 @@ def _declare(L):
                  "dsp_untile_dev", "dsp_sync_tiles_dev", "dsp_load_iq_i16", "dsp_load_iq_f32",
                  "dsp_fir_same_std", "dsp_rx_chain", "dsp_fir_tiles_dev", "dsp_synth_bursts_dev",
                  "dsp_sync_capture_segmented", "dsp_sync_capture_segmented_dev", "dsp_synth_stream_dev", "dsp_lagrange_resample", "dsp_fll_class", "dsp_diff_corr",
-                 "dsp_cfo_preamble", "dsp_cfo_fourth_power", "dsp_derotate", "dsp_rx_bursts", "dsp_cfo_derotate_dev", "dsp_fll_slicer"):
+                 "dsp_cfo_preamble", "dsp_cfo_fourth_power", "dsp_derotate", "dsp_rx_bursts", "dsp_cfo_derotate_dev", "dsp_fll_slicer", "dsp_trim"):
         getattr(L, name).restype = ci
 
 
@@ -230,6 +231,10 @@ class Context:
 
     def stream_copy(self, d_dst, d_src, nbytes):
         check(lib().dsp_stream_copy_dev(self.handle, C.c_void_p(d_dst), C.c_void_p(d_src), int(nbytes)))
+
+    def trim(self):
+        """Release the work buffers the segment-parallel calls keep between calls."""
+        check(lib().dsp_trim(self.handle))
 
     def timer_start(self):
         check(lib().dsp_timer_start(self.handle))

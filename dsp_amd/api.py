@@ -331,8 +331,25 @@ def rx_chain_batch(x, taps, sps=4, alpha=0.007, mu_initial=0.0, Bn=0.03, y=1, *,
     return bufs
 
 
+def auto_seg_len(n, sps, warmup):
+    """Segment length (samples) for a capture of n samples.  The recurrence is latency-bound (its
+    time follows the length of ONE window, about 0.7 us per symbol) until some 512 tiles of 64
+    windows are in flight, so: aim at 512 tiles, at most twice the warm-up long (8192 symbols
+    without one); a capture too short for that at one warm-up per segment keeps the segment at the
+    warm-up length (a window's warm-up rows are copied from its predecessor only while they fit
+    inside it), and a still shorter one goes down to a quarter of it, aiming at 128 tiles and
+    paying the filter for the overlap.  DESIGN.md 3.5 has the sweep behind these numbers."""
+    sps = int(sps)
+    lead = int(warmup) * sps
+    seg = (int(n) // (512 * 64)) // sps * sps
+    if seg >= lead:
+        return int(max(min(seg, max(2 * lead, 8192 * sps)), 1024 * sps))
+    seg = (int(n) // (128 * 64)) // sps * sps
+    return int(min(max(seg, lead // 4 // sps * sps, 256 * sps), max(lead, 256 * sps)))
+
+
 def sync_capture_segmented(x, sps=4, alpha=0.007, mu_initial=0.0, Bn=0.003, y=1, *, taps=None,
-                           seg_len=32768, warmup=4096, normalize=True, want=("dec", "mu", "freq"),
+                           seg_len=None, warmup=4096, normalize=True, want=("dec", "mu", "freq"),
                            acquire=True, ctx=None):
     """Segment-parallel Gardner + FLL + decisions over ONE long capture (no reference
     counterpart; north-star (c), include/dsp_hip.h dsp_sync_capture_segmented).
@@ -342,6 +359,7 @@ def sync_capture_segmented(x, sps=4, alpha=0.007, mu_initial=0.0, Bn=0.003, y=1,
     np.std over the whole capture (worker.py:173-178), None when x is already filtered.
     Returns a dict: dec uint8[n] quadrant indices, mu / freq float32[n] if wanted,
     seg_info int32[S, 4] = (first kept row, end row, rotation, rows produced) per segment.
+    seg_len: samples per segment, a multiple of sps (None: auto_seg_len).
     acquire (default): every window starts its timing loop at the sampling phase whose strobes carry
     the most energy over its first 256 symbols (mu_initial is then unused); False: at mu_initial.
     """
@@ -359,6 +377,8 @@ def sync_capture_segmented(x, sps=4, alpha=0.007, mu_initial=0.0, Bn=0.003, y=1,
         kind = DSP_C64
     if n == 0:
         raise IndexError("empty capture")                     # gardner2.py:59
+    if seg_len is None:
+        seg_len = auto_seg_len(n, sps, warmup)
     S = int(_lib.lib().dsp_capture_segments(n, int(seg_len)))
     cap = n // sps + 8 * max(S, 1) + 64
     dec = np.zeros(cap, np.uint8)

@@ -20,6 +20,10 @@ struct dsp_ctx {
     int split;          // -1 auto / 1: two waves per tile where applicable; 0: one wave per tile
     int queue_block;    // split kernel: symbols per hand-off block, 0 = automatic
     int prio_period;    // split kernel: priority rotation period in DMA blocks (power of two), 0 = off
+    // grow-only device scratch kept between calls of the segment-parallel mode (its window tiles are
+    // gigabytes: hipMalloc / hipFree per call cost milliseconds); released by dsp_trim / dsp_destroy
+    void *scratch[8];
+    size_t scratch_bytes[8];
 #ifdef DSP_TRACE
     unsigned long long *trace;
     int trace_stamps;
@@ -52,6 +56,33 @@ struct DevBuf {
     hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
     template <typename T> T *as() { return (T *)p; }
 };
+
+struct ScratchRef {
+    void *p = nullptr;
+    template <typename T> T *as() { return (T *)p; }
+};
+
+// a slot of the context's grow-only scratch, at least n bytes (contents undefined)
+static hipError_t ctx_scratch(dsp_ctx *c, int slot, size_t n, void **p)
+{
+    if (c->scratch_bytes[slot] < n) {
+        if (c->scratch[slot]) (void)hipFree(c->scratch[slot]);
+        c->scratch[slot] = nullptr; c->scratch_bytes[slot] = 0;
+        hipError_t e = hipMalloc(&c->scratch[slot], n);
+        if (e != hipSuccess) return e;
+        c->scratch_bytes[slot] = n;
+    }
+    *p = c->scratch[slot];
+    return hipSuccess;
+}
+
+static void ctx_trim(dsp_ctx *c)
+{
+    for (int i = 0; i < 8; i++) {
+        if (c->scratch[i]) (void)hipFree(c->scratch[i]);
+        c->scratch[i] = nullptr; c->scratch_bytes[i] = 0;
+    }
+}
 
 extern "C" {
 
@@ -102,10 +133,20 @@ void dsp_destroy(dsp_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    ctx_trim(c);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+int dsp_trim(dsp_ctx *c)
+{
+    if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    ctx_trim(c);
+    return DSP_OK;
 }
 
 int dsp_set_stream(dsp_ctx *c, void *s)
@@ -1178,13 +1219,14 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
     hipStream_t st = c->stream;
     HIP_TRY(hipSetDevice(c->device));
 
-    DevBuf d_starts, d_lens, d_tiles, d_mu, d_pos, d_dec, d_freq, d_nout, d_status, d_j0, d_j1, d_rot, d_pl, d_off;
+    DevBuf d_starts, d_lens, d_nout, d_status, d_j0, d_j1, d_rot, d_pl, d_off;
+    ScratchRef d_tiles, d_mu, d_pos, d_dec, d_freq;
     HIP_TRY(d_starts.alloc((size_t)S * 8)); HIP_TRY(d_lens.alloc((size_t)S * 4));
-    HIP_TRY(d_tiles.alloc((size_t)ntiles * rows * 64 * 8));
-    if (a->mu) HIP_TRY(d_mu.alloc((size_t)ntiles * out_rows * 64 * 4));
-    HIP_TRY(d_pos.alloc((size_t)ntiles * out_rows * 64 * 4));
-    HIP_TRY(d_dec.alloc((size_t)ntiles * out_rows * 64));
-    if (a->freq) HIP_TRY(d_freq.alloc((size_t)ntiles * out_rows * 64 * 4));
+    HIP_TRY(ctx_scratch(c, 0, (size_t)ntiles * rows * 64 * 8, &d_tiles.p));
+    if (a->mu) HIP_TRY(ctx_scratch(c, 1, (size_t)ntiles * out_rows * 64 * 4, &d_mu.p));
+    HIP_TRY(ctx_scratch(c, 2, (size_t)ntiles * out_rows * 64 * 4, &d_pos.p));
+    HIP_TRY(ctx_scratch(c, 3, (size_t)ntiles * out_rows * 64, &d_dec.p));
+    if (a->freq) HIP_TRY(ctx_scratch(c, 4, (size_t)ntiles * out_rows * 64 * 4, &d_freq.p));
     HIP_TRY(d_nout.alloc((size_t)S * 4)); HIP_TRY(d_status.alloc((size_t)S * 4));
     HIP_TRY(d_j0.alloc((size_t)S * 4)); HIP_TRY(d_j1.alloc((size_t)S * 4)); HIP_TRY(d_rot.alloc((size_t)S * 4));
     HIP_TRY(d_pl.alloc((size_t)S * 8)); HIP_TRY(d_off.alloc((size_t)(S + 1) * 8));

@@ -164,12 +164,16 @@ class CapturePipeline:
     decisions (and mu / frequency per symbol) stay on the device until fetch()."""
 
     def __init__(self, ctx, n_samples, sps=4, span=10, rolloff=0.35, alpha=0.007, mu0=0.0, Bn=0.003,
-                 y=1.0, seg_len=32768, warmup=4096, int16=True, matched_filter=True, want_mu=True,
+                 y=1.0, seg_len=None, warmup=4096, int16=True, matched_filter=True, want_mu=True,
                  want_freq=False, acquire=True):
         self.ctx, self.L = ctx, _lib.lib()
         self.n, self.sps = int(n_samples), int(sps)
         self.kind = DSP_I16 if int16 else DSP_C64
         self.taps = rrc_filter(sps, span, rolloff)
+        if seg_len is None:
+            from .api import auto_seg_len
+            seg_len = auto_seg_len(self.n, sps, warmup)
+        self.seg_len = int(seg_len)
         self.S = int(self.L.dsp_capture_segments(self.n, int(seg_len)))
         self.cap = self.n // self.sps + 8 * self.S + 64
         self._bufs = []

@@ -324,6 +324,9 @@ typedef struct dsp_capture_args {
     int32_t reserved;
 } dsp_capture_args;
 #define DSP_ACQUIRE_SYMBOLS 256
+/* The segment-parallel calls keep their large device work buffers (window tiles, per-window output
+ * tiles) in the context between calls; dsp_trim releases them (dsp_destroy does too).           */
+int dsp_trim(dsp_ctx *ctx);
 int dsp_sync_capture_segmented(dsp_ctx *ctx, const dsp_capture_args *args);
 int dsp_sync_capture_segmented_dev(dsp_ctx *ctx, const dsp_capture_args *args);
 int64_t dsp_capture_segments(int64_t n_samples, int64_t seg_len);   /* S = ceil(n / seg_len) */

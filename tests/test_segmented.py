@@ -201,3 +201,39 @@ def test_gpu_segmented_edge_shapes(oracle, stream, ctx):
         dsp_amd.sync_capture_segmented(y[:5000], SPS, seg_len=4098, ctx=ctx)      # not a multiple of sps
     with pytest.raises(IndexError):
         dsp_amd.sync_capture_segmented(np.zeros(0, np.complex64), SPS, ctx=ctx)
+
+
+def test_auto_seg_len_rule():
+    """auto_seg_len: a multiple of sps the C-ABI accepts, the warm-up shareable (lead <= seg_len)
+    from 2^28 samples on, 512 tiles aimed at for long captures."""
+    from dsp_amd.api import auto_seg_len
+    for sps in (2, 4, 5, 8):
+        for warm in (0, 100, 1024, 4096):
+            for lg in range(10, 34, 3):
+                s = auto_seg_len(1 << lg, sps, warm)
+                assert s % sps == 0 and s >= 16 * sps
+                if lg >= 28:
+                    assert s >= warm * sps
+    assert auto_seg_len(1 << 30, 4, 4096) == 32768
+    assert auto_seg_len(1 << 28, 4, 4096) == 16384
+    assert auto_seg_len(1 << 24, 4, 4096) == 4096
+
+
+@pytest.mark.gpu
+def test_capture_buffers_kept_and_trimmed(ctx, oracle, stream):
+    """The context keeps the mode's work buffers between calls: a larger call after a smaller one,
+    a smaller one after it, and a call after trim() all give the oracle's result; seg_len=None is
+    auto_seg_len."""
+    import dsp_amd
+    y = stream[3]
+    for n, seg_len in ((20000, 4096), (y.size, 8192), (9000, 2048)):
+        ref = oracle.sync_capture_segmented(y[:n], SPS, 0.007, 0.0, 0.003, 1.0, seg_len=seg_len, warmup=512)
+        got = dsp_amd.sync_capture_segmented(y[:n], SPS, 0.007, 0.0, 0.003, 1, seg_len=seg_len, warmup=512, ctx=ctx)
+        assert got["n"] == ref["n"] and np.array_equal(got["dec"], ref["dec"])
+        assert np.array_equal(got["seg_info"], ref["seg_info"])
+        if n == y.size:
+            ctx.trim()
+    auto = dsp_amd.sync_capture_segmented(y, SPS, 0.007, 0.0, 0.003, 1, warmup=512, ctx=ctx)
+    ref = oracle.sync_capture_segmented(y, SPS, 0.007, 0.0, 0.003, 1.0, warmup=512,
+                                        seg_len=dsp_amd.api.auto_seg_len(y.size, SPS, 512))
+    assert auto["n"] == ref["n"] and np.array_equal(auto["dec"], ref["dec"])

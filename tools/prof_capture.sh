@@ -1,0 +1,21 @@
+# rocprofv3 kernel stats of tools/bench_capture.py on the GPU box:
+#   bash tools/prof_capture.sh <log2_samples> <seg_len, 0 = auto> <tag>
+# leaves gpurun_out/cap/kstats_<tag>.csv, gpurun_out/cap/kstats_<tag>.txt (the table kept under profiles/)
+set -e
+R=$PWD; mkdir -p $R/gpurun_out/cap
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d /tmp/pc_$3 -o p --output-format csv -- python3 $R/tools/bench_capture.py $1 $2 > $R/gpurun_out/cap/prof_$3.log 2>&1
+f=$(find /tmp/pc_$3 -name '*kernel_stats.csv' | head -1)
+cp $f $R/gpurun_out/cap/kstats_$3.csv
+python3 - $R/gpurun_out/cap/kstats_$3.csv $R/gpurun_out/cap/prof_$3.log > $R/gpurun_out/cap/kstats_$3.txt <<'PY'
+import csv, json, sys
+line = [l for l in open(sys.argv[2]) if l.startswith("{")][-1]
+d = json.loads(line)
+print("workload:", d["workload"])
+print("whole call under the profiler (HIP events around dsp_sync_capture_segmented_dev): %.2f ms, %d windows" % (d["ms"], d["segments"]))
+print()
+print("%-100s %5s %9s %7s" % ("kernel", "calls", "avg ms", "%"))
+for r in csv.DictReader(open(sys.argv[1])):
+    print("%-100s %5s %9.3f %7.2f" % (r["Name"][:98], r["Calls"], float(r["AverageNs"]) / 1e6, float(r["Percentage"])))
+PY
+cat $R/gpurun_out/cap/kstats_$3.txt
