@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--split", type=int, default=-1, help="-1 auto, 0 one wave per tile, 1 two")
     ap.add_argument("--prio-period", type=int, default=0, help="priority rotation period (DMA blocks)")
     ap.add_argument("--queue-block", type=int, default=0, help="split kernel hand-off block (0 auto)")
+    ap.add_argument("--spare-wave", type=int, default=-1, help="split kernel: idle middle wave per tile (1, default) or not (0)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -123,6 +124,8 @@ def main():
         ctx.set_option("prio_period", args.prio_period)
     if args.queue_block:
         ctx.set_option("queue_block", args.queue_block)
+    if args.spare_wave >= 0:
+        ctx.set_option("spare_wave", args.spare_wave)
     B = args.bursts
     b_lo, b_hi = shard_range(B * world, rank, world)      # this rank's bursts of the whole job
 

@@ -19,6 +19,7 @@ struct dsp_ctx {
     int lds_pad;        // extra dynamic LDS per workgroup (bytes) to steer workgroups per CU
     int split;          // -1 auto / 1: two waves per tile where applicable; 0: one wave per tile
     int queue_block;    // split kernel: symbols per hand-off block, 0 = automatic
+    int spare_wave;     // split kernel: 3 waves per tile with the middle one idle: -1 auto, 0 never, 1 always
     int prio_period;    // split kernel: priority rotation period in DMA blocks (power of two), 0 = off
     // grow-only device scratch kept between calls of the segment-parallel mode (its window tiles are
     // gigabytes: hipMalloc / hipFree per call cost milliseconds); released by dsp_trim / dsp_destroy
@@ -113,6 +114,7 @@ int dsp_create(int device_id, dsp_ctx **out)
     c->split = -1;
     c->queue_block = 0;
     c->prio_period = 0;
+    c->spare_wave = -1;
 #ifdef DSP_TRACE
     c->trace = nullptr;
     c->trace_stamps = 0;
@@ -183,6 +185,9 @@ int dsp_set_option(dsp_ctx *c, const char *name, int64_t value)
     } else if (!strcmp(name, "trace_stamps")) {
         c->trace_stamps = (int)value;
 #endif
+    } else if (!strcmp(name, "spare_wave")) {
+        if (value < -1 || value > 1) return fail(DSP_E_ARG, "spare_wave must be -1 (auto), 0 or 1");
+        c->spare_wave = (int)value;
     } else if (!strcmp(name, "prio_period")) {
         if (value < 0 || value > 4096 || (value & (value - 1))) return fail(DSP_E_ARG, "prio_period must be 0 or a power of two");
         c->prio_period = (int)value;
@@ -421,6 +426,10 @@ int dsp_sync_tiles_dev(dsp_ctx *c, const dsp_sync_args *a)
         while (TQ > 1 && lds + (size_t)2 * TQ * 64 * 17 + 16 > room) TQ--;
         P.TQ = TQ;
         P.prio_period = c->prio_period;
+        // two 2-wave workgroups per CU land on three SIMDs (sync_kernels.hip); the idle middle wave
+        // spreads them over four.  Measured: 512 tiles 1.57 -> 1.30 ms; no gain at one workgroup per
+        // CU, 3 % slower at three or four, and at eight the spare waves cost occupancy
+        P.spare_wave = c->spare_wave >= 0 ? c->spare_wave : (per_cu == 2 ? 1 : 0);
         lds += (size_t)2 * TQ * 64 * 17 + 16;
     }
     if (c->lds_pad >= 0) lds += (size_t)c->lds_pad;

@@ -43,6 +43,7 @@ struct SyncParams {
     // LDS ring schedule (host-computed, see sync_plan())
     int use_ring, ring_rows, T, C, nwait;
     int TQ;                   // > 0: split kernel, queue block length (iterations)
+    int spare_wave;           // split kernel: 1 = launch 3 waves per tile, the middle one idle (SIMD balance)
     int prio_period;          // split kernel: rotate the wave priority every this many DMA blocks (power of 2, 0 = off)
 #ifdef DSP_TRACE
     unsigned long long *trace; // diagnostic build only: [tile][role][20] = start, end (s_memtime), HW_ID, XCC_ID, 16 segment sums

@@ -24,7 +24,7 @@ def _match_rates(dec, seed, b0, skip=400):
     return out
 
 
-@pytest.mark.parametrize("B,split", [(4096, 1), (4096, 0), (65536, -1)])
+@pytest.mark.parametrize("B,split", [(4096, 1), (4096, 0), (32768, -1), (65536, -1)])
 def test_pipeline_fullsize(ctx, oracle, B, split):
     from dsp_amd.pipeline import BurstPipeline
     ctx.set_option("split", split)

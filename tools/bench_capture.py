@@ -52,6 +52,9 @@ def main():
     n, sps = 1 << lg, 4
     tau0, drift = 0.3, 2.0e-8
     ctx = dsp_amd.Context(0)
+    for kv in os.environ.get("DSP_CAPTURE_OPTS", "").split(","):      # e.g. ring_rows=256,queue_block=32
+        if kv:
+            ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     pipe = CapturePipeline(ctx, n, sps, seg_len=seg_len, warmup=warmup)
     pipe.generate(SEED, tau0=tau0, drift=drift)
     ctx.synchronize()
