@@ -346,13 +346,39 @@ __global__ void burst_cast_kernel(const d2v *__restrict__ src, int64_t src_ld, f
 
 // ---- raw IQ loaders (hw1/gardner.py:77-91) -----------------------------------
 // peak^2 = max(i^2 + q^2) over the capture, exact in integers
-__global__ void iq_i16_peak_kernel(const s2v *__restrict__ raw, int64_t n, unsigned *__restrict__ peak2)
+__device__ __forceinline__ unsigned iq_mag2(unsigned w)
+{
+    const int a = (short)(w & 0xffffu), c = (short)(w >> 16);
+    return (unsigned)(a * a) + (unsigned)(c * c);
+}
+// max |i + jq|^2 over the capture: a read-only stream, 16-byte loads (4 samples), 4 of them in flight
+// per lane; the few samples before the first 16-byte boundary and after the last whole word go one
+// by one.  raw is 4-byte aligned (one IQ pair).
+__global__ __launch_bounds__(256) void iq_i16_peak_kernel(const s2v *__restrict__ raw, int64_t n, unsigned *__restrict__ peak2)
 {
     unsigned m = 0;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int a = raw[i].x, c = raw[i].y;
-        const unsigned v = (unsigned)(a * a) + (unsigned)(c * c);
-        m = v > m ? v : m;
+    const unsigned *w = (const unsigned *)raw;
+    int64_t head = (int64_t)(((16 - ((uintptr_t)raw & 15)) & 15) >> 2);
+    if (head > n) head = n;
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    const u4v *body = (const u4v *)(w + head);
+    const int64_t nq = (n - head) >> 2, tail0 = head + 4 * nq;
+    const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+    if (tid < head) m = iq_mag2(w[tid]);
+    if (tail0 + tid < n) { const unsigned v = iq_mag2(w[tail0 + tid]); m = v > m ? v : m; }   // < 4 samples
+    for (int64_t i = tid; i < nq; i += 4 * nthr) {
+        u4v v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int64_t j = i + u * nthr;
+            v[u] = j < nq ? __builtin_nontemporal_load(body + j) : u4v{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const unsigned a0 = iq_mag2(v[u].x), a1 = iq_mag2(v[u].y), a2 = iq_mag2(v[u].z), a3 = iq_mag2(v[u].w);
+            const unsigned b0 = a0 > a1 ? a0 : a1, b1 = a2 > a3 ? a2 : a3, c0 = b0 > b1 ? b0 : b1;
+            m = c0 > m ? c0 : m;
+        }
     }
     for (int off = 32; off > 0; off >>= 1) {
         const unsigned o = __shfl_down(m, off);
@@ -492,7 +518,10 @@ hipError_t launch_iq_i16(const void *raw, int64_t n, int normalize, unsigned *pe
     int blocks = (int)((n + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    if (normalize) hipLaunchKernelGGL(iq_i16_peak_kernel, dim3(blocks), dim3(256), 0, s, (const s2v *)raw, n, peak2);
+    int pblocks = (int)((n / 4 + 1023) / 1024);          // 4 x 16 bytes per lane and pass
+    if (pblocks > 8192) pblocks = 8192;
+    if (pblocks < 1) pblocks = 1;
+    if (normalize) hipLaunchKernelGGL(iq_i16_peak_kernel, dim3(pblocks), dim3(256), 0, s, (const s2v *)raw, n, peak2);
     hipLaunchKernelGGL(iq_i16_scale_kernel, dim3(1), dim3(1), 0, s, peak2, normalize, iscale);
     if (out) hipLaunchKernelGGL(iq_i16_convert_kernel, dim3(blocks), dim3(256), 0, s, (const s2v *)raw, n, iscale, (f2v *)out);
     return hipGetLastError();

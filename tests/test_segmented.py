@@ -237,3 +237,44 @@ def test_capture_buffers_kept_and_trimmed(ctx, oracle, stream):
     ref = oracle.sync_capture_segmented(y, SPS, 0.007, 0.0, 0.003, 1.0, warmup=512,
                                         seg_len=dsp_amd.api.auto_seg_len(y.size, SPS, 512))
     assert auto["n"] == ref["n"] and np.array_equal(auto["dec"], ref["dec"])
+
+
+@pytest.mark.gpu
+def test_capture_int16_pointer_alignment(ctx):
+    """The device-pointer entry point takes any IQ-pair-aligned (4-byte) capture pointer: the peak
+    search reads 16-byte words between a head and a tail, the filter stages from arbitrary window
+    starts.  Same capture at byte offsets 0, 4, 8, 12 and with lengths that leave 0..3 samples after
+    the last whole word -> the same decisions; the peak sample sits in the head / tail once each."""
+    from dsp_amd.pipeline import CapturePipeline
+    rng = np.random.default_rng(99)
+    n = 60000 + 3
+    q, x, h = make_stream(n // SPS + 1, seed=5)
+    x = x[:n]
+    iq = np.empty(2 * n, np.int16)
+    iq[0::2] = np.clip(np.rint(x.real * 4000), -32767, 32767)
+    iq[1::2] = np.clip(np.rint(x.imag * 4000), -32767, 32767)
+    ref = {}
+    for cut in (0, 1, 2, 3):
+        for where in ("none", "head", "tail"):
+            m = n - cut
+            w = iq[:2 * m].copy()
+            if where == "head":
+                w[0] = 32767
+            elif where == "tail":
+                w[2 * m - 1] = -32768
+            for off in (0, 1, 2, 3):
+                pipe = CapturePipeline(ctx, m + 4, SPS, seg_len=8192, warmup=512, want_freq=True)
+                pipe.n = m
+                pipe.S = -(-m // 8192)
+                pipe.info = np.zeros((pipe.S, 4), np.int32)
+                pipe._args.seg_info = pipe.info.ctypes.data
+                pipe._args.n_samples = m
+                pipe._args.x = pipe.d_x + 4 * off
+                ctx.h2d(pipe.d_x + 4 * off, w)
+                ns = pipe.run()
+                got = (ns, pipe.fetch("dec").tobytes(), pipe.fetch("mu").tobytes(), pipe.fetch("freq").tobytes())
+                pipe.close()
+                if off == 0:
+                    ref[(cut, where)] = got
+                assert got == ref[(cut, where)], (cut, where, off)
+    assert ref[(0, "none")][1] != ref[(0, "head")][1] or ref[(0, "none")][2] != ref[(0, "head")][2]
