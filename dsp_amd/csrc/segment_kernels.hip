@@ -255,14 +255,27 @@ __global__ __launch_bounds__(256) void seg_gather_k(SegParams P, uint8_t *__rest
         }
         if (r0 + 64 <= lo || r0 >= hi) return;          // uniform over the workgroup
     }
-    for (int i = 0; i < 16; i++) {
-        const int rr = w * 16 + i, row = r0 + rr;
-        if (row < P.out_rows) {
-            const size_t at = ((size_t)tile * P.out_rows + row) * 64 + lane;
-            td[rr][lane] = P.dec[at];
+    {
+        // all of a wave's loads first (16 rows x 3 arrays in flight), then the LDS stores
+        uint8_t vd[16];
+        float vm[16], vf[16];
+        const size_t at0 = ((size_t)tile * P.out_rows + r0 + w * 16) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int row = r0 + w * 16 + i;
+            const bool ok = row < P.out_rows;
+            const size_t at = at0 + (size_t)i * 64;
+            vd[i] = ok ? P.dec[at] : (uint8_t)0;
             // mu history row r-1 belongs to symbol row r
-            if (mu_out) tm[rr][lane] = row > 0 ? ((const float *)P.mu)[at - 64] : 0.0f;
-            if (freq_out) tf[rr][lane] = ((const float *)P.freq)[at];
+            vm[i] = (mu_out && ok && row > 0) ? ((const float *)P.mu)[at - 64] : 0.0f;
+            vf[i] = (freq_out && ok) ? ((const float *)P.freq)[at] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int rr = w * 16 + i;
+            td[rr][lane] = vd[i];
+            tm[rr][lane] = vm[i];
+            tf[rr][lane] = vf[i];
         }
     }
     __syncthreads();
