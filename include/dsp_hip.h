@@ -51,7 +51,9 @@ int dsp_set_stream(dsp_ctx *ctx, void *hip_stream);      /* adopt an external hi
 int dsp_synchronize(dsp_ctx *ctx);
 int dsp_set_option(dsp_ctx *ctx, const char *name, int64_t value); /* tuning knobs: "ring_rows" (LDS ring rows, 0 auto),
    "lds_pad", "split" (-1 auto / 0 one wave per tile / 1 two), "queue_block" (hand-off block, 0 auto),
-   "prio_period" (rotate wave priorities every N DMA blocks, 0 off) */
+   "prio_period" (rotate wave priorities every N DMA blocks, 0 off), "spare_wave" (two-wave kernel
+   launched with an idle middle wave so that two workgroups on a CU use four SIMDs: -1 auto = at two
+   workgroups per CU, 0 never, 1 always) */
 
 /* ---- device memory and timing (for *_dev pipelines and bench.py) ---------- */
 int dsp_malloc(dsp_ctx *ctx, size_t bytes, void **dptr);
