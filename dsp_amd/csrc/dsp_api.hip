@@ -19,6 +19,7 @@ struct dsp_ctx {
     int lds_pad;        // extra dynamic LDS per workgroup (bytes) to steer workgroups per CU
     int split;          // -1 auto / 1: two waves per tile where applicable; 0: one wave per tile
     int queue_block;    // split kernel: symbols per hand-off block, 0 = automatic
+    int lead_copy;      // segment-parallel mode, warm-up rows: 0 = the filter's second store, 1 = seg_lead_copy_k, 2 = filtered per window
     int spare_wave;     // split kernel: 3 waves per tile with the middle one idle: -1 auto, 0 never, 1 always
     int prio_period;    // split kernel: priority rotation period in DMA blocks (power of two), 0 = off
     // grow-only device scratch kept between calls of the segment-parallel mode (its window tiles are
@@ -115,6 +116,7 @@ int dsp_create(int device_id, dsp_ctx **out)
     c->queue_block = 0;
     c->prio_period = 0;
     c->spare_wave = -1;
+    c->lead_copy = 0;
 #ifdef DSP_TRACE
     c->trace = nullptr;
     c->trace_stamps = 0;
@@ -185,6 +187,9 @@ int dsp_set_option(dsp_ctx *c, const char *name, int64_t value)
     } else if (!strcmp(name, "trace_stamps")) {
         c->trace_stamps = (int)value;
 #endif
+    } else if (!strcmp(name, "lead_copy")) {
+        if (value < 0 || value > 2) return fail(DSP_E_ARG, "lead_copy must be 0, 1 or 2");
+        c->lead_copy = (int)value;
     } else if (!strcmp(name, "spare_wave")) {
         if (value < -1 || value > 1) return fail(DSP_E_ARG, "spare_wave must be -1 (auto), 0 or 1");
         c->spare_wave = (int)value;
@@ -1274,10 +1279,12 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
         Q.in_scale = in_scale; Q.dst = d_tiles.p; Q.rows = (int)rows; Q.stats = d_ws.as<double>();
         // the warm-up rows of a window are rows its predecessor filters anyway: skip them here (every
         // tile but the first) and copy them over afterwards
-        const bool share_lead = lead > 0 && lead <= seg && S > 64;
+        const bool share_lead = lead > 0 && lead <= seg && S > 64 && c->lead_copy != 2;
         Q.skip_rows = share_lead ? (int)lead : 0;
+        Q.feed_lead = share_lead && c->lead_copy == 0 ? 1 : 0;     // the predecessor's workgroup stores them ...
         HIP_TRY(launch_fir_tile(Q, a->in_kind, st));
-        if (share_lead) HIP_TRY(launch_seg_lead_copy(d_tiles.p, (int)rows, d_starts.as<int64_t>(), S, (int)lead, st));
+        if (share_lead && c->lead_copy == 1)                      // ... or a copy kernel does afterwards
+            HIP_TRY(launch_seg_lead_copy(d_tiles.p, (int)rows, d_starts.as<int64_t>(), S, (int)lead, st));
         HIP_TRY(launch_fir_stats_global(Q.stats, (int64_t)S * Q.nchunk, S, nullptr, d_inv.as<double>(),
                                         d_part.as<double>(), 1024, st));
         d_scale = d_inv.as<double>();

@@ -53,6 +53,16 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
             double *st = P.stats + ((size_t)sb * P.nchunk + chunk) * 4;
             st[0] = 0.0; st[1] = 0.0; st[2] = 0.0; st[3] = 0.0;
         }
+        // the predecessors' workgroups store these rows (feed_lead); the idle lanes of the last tile
+        // have no predecessor: clear them (the recurrence kernel loads whole rows)
+        const int idle0 = P.B - tile * 64;
+        if (P.feed_lead && P.dst && idle0 < 64) {
+            OUT *d = (OUT *)P.dst + (size_t)tile * P.rows * 64;
+            for (int i = threadIdx.x; i < CH * 64; i += 256) {
+                const int r = n0 + (i >> 6), l = i & 63;
+                if (l >= idle0 && r < P.rows) put(d + (size_t)r * 64 + l, 0.0, 0.0);
+            }
+        }
         return;
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -110,6 +120,15 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
     const int st_hi = (P.stat_hi && b < P.B) ? P.stat_hi[b] : len;
     const ST *xrow = xs + (size_t)lane * stride;
     OUT *dst = P.dst ? (OUT *)P.dst + (size_t)tile * P.rows * 64 + lane : nullptr;
+    // segment-parallel mode: this window's rows [shift, shift + skip_rows) are the warm-up rows
+    // [0, skip_rows) of its successor (the same samples, hence the same sums): store them there too
+    OUT *feed = nullptr;
+    int feed_lo = 0;
+    if (P.feed_lead && P.dst && b + 1 < P.B && b + 1 >= 64) {
+        feed_lo = (int)(P.starts[b + 1] - P.starts[b]);
+        feed = (OUT *)P.dst + (size_t)((b + 1) >> 6) * P.rows * 64 + ((b + 1) & 63) - (ptrdiff_t)feed_lo * 64;
+    }
+    const int feed_hi = feed_lo + P.skip_rows;
     const int per_wave = CH / 4;
     double s_re = 0.0, s_im = 0.0;      // sums of this lane's valid outputs
     int cnt = 0;
@@ -146,6 +165,8 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
                 if (counts) { s_re += are[o]; s_im += aim[o]; cnt++; }
                 if (dst && n < P.rows) put(dst + (size_t)n * 64, valid ? are[o] * scale : 0.0,
                                            valid ? aim[o] * scale : 0.0);
+                if (feed && n >= feed_lo && n < feed_hi) put(feed + (ptrdiff_t)n * 64, valid ? are[o] * scale : 0.0,
+                                                             valid ? aim[o] * scale : 0.0);
             }
         }
     }

@@ -278,3 +278,40 @@ def test_capture_int16_pointer_alignment(ctx):
                     ref[(cut, where)] = got
                 assert got == ref[(cut, where)], (cut, where, off)
     assert ref[(0, "none")][1] != ref[(0, "head")][1] or ref[(0, "none")][2] != ref[(0, "head")][2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_keep", [100 * 2048, 130 * 2048 - 700])
+def test_gpu_shared_warmup_rows_bit_identical(oracle, ctx, n_keep):
+    """More than 64 windows with the matched filter: a window's warm-up rows come from its
+    predecessor (stored by the predecessor's filter workgroup, or copied afterwards) instead of being
+    filtered again.  All three ways give the same bits; the result follows the oracle as closely as
+    the per-window filter does (test_gpu_segmented_int16_with_matched_filter)."""
+    import dsp_amd
+    q, x, h = make_stream(n_keep // SPS + 64, seed=23)
+    x = x[:n_keep]
+    pk = np.max(np.abs(np.concatenate((x.real, x.imag))))
+    w = np.empty(2 * x.size, np.int16)
+    w[0::2] = np.round(x.real / pk * 20000)
+    w[1::2] = np.round(x.imag / pk * 20000)
+    outs = []
+    try:
+        for mode in (2, 1, 0):
+            ctx.set_option("lead_copy", mode)
+            outs.append(dsp_amd.sync_capture_segmented(w, SPS, 0.007, 0.0, 0.003, 1, taps=h, seg_len=2048, warmup=256,
+                                                       ctx=ctx))
+    finally:
+        ctx.set_option("lead_copy", 0)
+    assert outs[0]["seg_info"].shape[0] > 64
+    for o in outs[1:]:
+        assert o["n"] == outs[0]["n"]
+        for k in ("dec", "mu", "freq", "seg_info"):
+            assert np.array_equal(o[k], outs[0][k]), k
+    xc = oracle.read_iq_int16_words(w, True)
+    yf = oracle.convolve_same(xc, h)
+    ref = oracle.sync_capture_segmented(yf.astype(np.complex64), SPS, 0.007, 0.0, 0.003, 1.0, seg_len=2048, warmup=256,
+                                        scale=1.0 / oracle.np_std(yf))
+    assert outs[0]["n"] == ref["n"]
+    assert np.mean(outs[0]["dec"] == ref["dec"]) > 0.9999
+    n = min(ref["n"], q.size)
+    assert best_rotation_match(outs[0]["dec"][500:n], q[500:n]) > 0.999
