@@ -55,6 +55,7 @@ KERNEL(k_bfi_dep, 1, "v_bfi_b32 %6, %7, %6, %4")
 KERNEL(k_lshladd64, 1, "v_lshl_add_u64 %0, %0, 0, %1")
 KERNEL(k_cvt_f64_i32, 2, "v_cvt_f64_i32 %0, %6\n v_cvt_i32_f64 %6, %0")
 KERNEL(k_cvt_f64_f32, 2, "v_cvt_f64_f32 %0, %4\n v_cvt_f32_f64 %4, %0")
+KERNEL(k_cvt64_4, 4, "v_cvt_f64_f32 %0, %4\n v_cvt_f64_f32 %1, %5\n v_cvt_f64_f32 %2, %4\n v_cvt_f64_f32 %3, %5")
 KERNEL(k_fract64, 1, "v_fract_f64 %0, %0")
 KERNEL(k_rndne64, 1, "v_rndne_f64 %0, %0")
 KERNEL(k_ldexp64, 1, "v_ldexp_f64 %0, %0, 1")
@@ -97,7 +98,7 @@ int main()
         C(k_fma64_dep, 1), C(k_fma64_2, 2), C(k_fma64_4, 4), C(k_add64_dep, 1), C(k_mul64_dep, 1), C(k_mul64_4, 4),
         C(k_fma32_dep, 1), C(k_fma32_2, 2), C(k_cnd_vcc_dep, 1), C(k_cnd_vcc_2, 2), C(k_cnd_sgpr_dep, 1),
         C(k_cnd_sgpr_2, 2), C(k_mov_dep, 1), C(k_and_dep, 1), C(k_and_2, 2), C(k_addu_dep, 1), C(k_bfi_dep, 1),
-        C(k_lshladd64, 1), C(k_cvt_f64_i32, 2), C(k_cvt_f64_f32, 2), C(k_fract64, 1), C(k_rndne64, 1),
+        C(k_lshladd64, 1), C(k_cvt_f64_i32, 2), C(k_cvt_f64_f32, 2), C(k_cvt64_4, 4), C(k_fract64, 1), C(k_rndne64, 1),
         C(k_ldexp64, 1), C(k_rcp64, 1), C(k_cmp64_cnd, 2), C(k_cmp64_only, 1), C(k_cmp32_only, 1),
         C(k_cmp64_sgpr, 1), C(k_mul_lo, 1), C(k_fma64_snop, 2), C(k_fma64_fma32, 2),
         C(k_pk_fma32, 1), C(k_ds_read, 1), C(k_cmp_sand_cnd, 3), C(k_cmp_cnd_e64, 2), C(k_cmp_cnd_dep, 2),
