@@ -64,6 +64,18 @@ struct ScratchRef {
     template <typename T> T *as() { return (T *)p; }
 };
 
+struct Bump {                    // sub-allocation of one scratch block, 256-byte aligned
+    char *base = nullptr;
+    size_t off = 0, cap = 0;
+    void *take(size_t n)
+    {
+        off = (off + 255) & ~(size_t)255;
+        void *p = base + off;
+        off += n ? n : 16;
+        return p;
+    }
+};
+
 // a slot of the context's grow-only scratch, at least n bytes (contents undefined)
 static hipError_t ctx_scratch(dsp_ctx *c, int slot, size_t n, void **p)
 {
@@ -1233,32 +1245,39 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
     hipStream_t st = c->stream;
     HIP_TRY(hipSetDevice(c->device));
 
-    DevBuf d_starts, d_lens, d_nout, d_status, d_j0, d_j1, d_rot, d_pl, d_off;
+    // every per-window array comes out of one block of the context's scratch (slot 5), the large
+    // tiles have slots of their own: no hipMalloc / hipFree in a call once the context has grown
+    ScratchRef d_starts, d_lens, d_nout, d_status, d_j0, d_j1, d_rot, d_pl, d_off;
     ScratchRef d_tiles, d_mu, d_pos, d_dec, d_freq;
-    HIP_TRY(d_starts.alloc((size_t)S * 8)); HIP_TRY(d_lens.alloc((size_t)S * 4));
+    Bump small;
+    small.cap = (size_t)64 * 1024 + (size_t)S * 96;
+    HIP_TRY(ctx_scratch(c, 5, small.cap, (void **)&small.base));
+    d_starts.p = small.take((size_t)S * 8); d_lens.p = small.take((size_t)S * 4);
     HIP_TRY(ctx_scratch(c, 0, (size_t)ntiles * rows * 64 * 8, &d_tiles.p));
     if (a->mu) HIP_TRY(ctx_scratch(c, 1, (size_t)ntiles * out_rows * 64 * 4, &d_mu.p));
     HIP_TRY(ctx_scratch(c, 2, (size_t)ntiles * out_rows * 64 * 4, &d_pos.p));
     HIP_TRY(ctx_scratch(c, 3, (size_t)ntiles * out_rows * 64, &d_dec.p));
     if (a->freq) HIP_TRY(ctx_scratch(c, 4, (size_t)ntiles * out_rows * 64 * 4, &d_freq.p));
-    HIP_TRY(d_nout.alloc((size_t)S * 4)); HIP_TRY(d_status.alloc((size_t)S * 4));
-    HIP_TRY(d_j0.alloc((size_t)S * 4)); HIP_TRY(d_j1.alloc((size_t)S * 4)); HIP_TRY(d_rot.alloc((size_t)S * 4));
-    HIP_TRY(d_pl.alloc((size_t)S * 8)); HIP_TRY(d_off.alloc((size_t)(S + 1) * 8));
+    // j0 | j1 | rot | n_out lie back to back: one copy brings seg_info home
+    d_j0.p = small.take((size_t)S * 16);
+    d_j1.p = d_j0.as<int>() + S; d_rot.p = d_j0.as<int>() + 2 * (size_t)S; d_nout.p = d_j0.as<int>() + 3 * (size_t)S;
+    d_status.p = small.take((size_t)S * 4);
+    d_pl.p = small.take((size_t)S * 8); d_off.p = small.take((size_t)(S + 1) * 8);
     // the filter pass writes every row of every lane (zeros past a window's end and in the idle lanes
     // of the last tile: its chunks cover ceil(Nw / CH) * CH >= rows); only the copy path needs clearing
     if (!a->h) HIP_TRY(hipMemsetAsync(d_tiles.p, 0, (size_t)ntiles * rows * 64 * 8, st));
 
     // ---- windows -> tiles (optionally through the matched filter) ------------------------
-    DevBuf d_peak, d_c64, d_ws, d_inv, d_lo, d_hi, d_part;
+    ScratchRef d_peak, d_c64, d_ws, d_inv, d_lo, d_hi, d_part;
     const float *in_scale = nullptr;
     if (a->in_kind == DSP_I16) {
-        HIP_TRY(d_peak.alloc(16));
-        if (!a->h) HIP_TRY(d_c64.alloc((size_t)n * 8));
+        d_peak.p = small.take(16);
+        if (!a->h) HIP_TRY(ctx_scratch(c, 7, (size_t)n * 8, &d_c64.p));
         HIP_TRY(launch_iq_i16(a->x, n, a->normalize, d_peak.as<unsigned>(), d_peak.as<float>() + 1,
                               a->h ? nullptr : d_c64.p, st));
         in_scale = d_peak.as<float>() + 1;
     }
-    HIP_TRY(d_lo.alloc((size_t)S * 4)); HIP_TRY(d_hi.alloc((size_t)S * 4));
+    d_lo.p = small.take((size_t)S * 4); d_hi.p = small.take((size_t)S * 4);
     HIP_TRY(launch_seg_windows(S, n, seg, lead, tail, d_starts.as<int64_t>(), d_lens.as<int>(), d_lo.as<int>(),
                                d_hi.as<int>(), st));
     const double *d_scale = nullptr;
@@ -1270,9 +1289,9 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
         memset(&Q, 0, sizeof(Q));
         if (!fir_plan(a->in_kind, a->n_taps, (int)Nw, Q))
             return fail(DSP_E_ARG, "capture: %d taps are too many for the LDS-tiled filter", a->n_taps);
-        HIP_TRY(d_ws.alloc((size_t)S * Q.nchunk * 32));
-        HIP_TRY(d_inv.alloc((size_t)S * 8));
-        HIP_TRY(d_part.alloc((size_t)1024 * 32));
+        HIP_TRY(ctx_scratch(c, 6, (size_t)S * Q.nchunk * 32, &d_ws.p));
+        d_inv.p = small.take((size_t)S * 8);
+        d_part.p = small.take((size_t)1024 * 32);
         Q.src = a->x; Q.starts = d_starts.as<int64_t>(); Q.n_total = n; Q.lens = d_lens.as<int>();
         Q.stat_lo = d_lo.as<int>(); Q.stat_hi = d_hi.as<int>();
         Q.len_all = (int)Nw; Q.B = S; Q.h = a->h; Q.M = a->n_taps; Q.start = (a->n_taps - 1) / 2;
@@ -1294,10 +1313,11 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
                                         d_starts.as<int64_t>()));
     }
 
+    if (small.off > small.cap) return fail(DSP_E_NOMEM, "capture: scratch block too small");
     // ---- initial timing phase per window (strobe energy), unless the caller fixes mu0 ------------
-    DevBuf d_mu0;
+    ScratchRef d_mu0;
     if (a->acquire) {
-        HIP_TRY(d_mu0.alloc((size_t)S * 8));
+        d_mu0.p = small.take((size_t)S * 8);
         HIP_TRY(launch_seg_phase(d_tiles.p, (int)rows, d_lens.as<int>(), S, sps, DSP_ACQUIRE_SYMBOLS,
                                  d_mu0.as<double>(), st));
     }
@@ -1330,15 +1350,12 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
     int64_t total = 0;
     HIP_TRY(hipMemcpyAsync(&total, d_off.as<int64_t>() + S, 8, hipMemcpyDeviceToHost, st));
     if (a->seg_info) {
-        std::vector<int32_t> j0(S), j1(S), rot(S), no(S);
-        HIP_TRY(hipMemcpyAsync(j0.data(), d_j0.p, (size_t)S * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(j1.data(), d_j1.p, (size_t)S * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(rot.data(), d_rot.p, (size_t)S * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(no.data(), d_nout.p, (size_t)S * 4, hipMemcpyDeviceToHost, st));
+        std::vector<int32_t> info((size_t)S * 4);            // [j0 | j1 | rot | n_out]
+        HIP_TRY(hipMemcpyAsync(info.data(), d_j0.p, (size_t)S * 16, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        for (int s = 0; s < S; s++) {
-            a->seg_info[4 * s] = j0[s]; a->seg_info[4 * s + 1] = j1[s];
-            a->seg_info[4 * s + 2] = rot[s]; a->seg_info[4 * s + 3] = no[s];
+        for (size_t s = 0; s < (size_t)S; s++) {
+            a->seg_info[4 * s] = info[s]; a->seg_info[4 * s + 1] = info[S + s];
+            a->seg_info[4 * s + 2] = info[2 * (size_t)S + s]; a->seg_info[4 * s + 3] = info[3 * (size_t)S + s];
         }
     }
     HIP_TRY(hipStreamSynchronize(st));
