@@ -111,16 +111,18 @@ __global__ __launch_bounds__(64) void seg_range_k(SegParams P, int vote_len)
         int V = vote_len;
         if (V > j0) V = j0;
         if (V > jp) V = jp;
-        int best = -1;
-        for (int r4 = 0; r4 < 4; r4++) {
-            int agree = 0;
-            for (int m = 0; m < V; m++) {
-                const unsigned a = rot_quadrant(tile_u8(P.dec, P.out_rows, s, j0 - 1 - m), r4);
-                const unsigned b = tile_u8(P.dec, P.out_rows, s - 1, jp - 1 - m);
-                agree += a == b;
-            }
-            if (agree > best) { best = agree; rot = r4; }
+        // every pair of decisions agrees under exactly one of the four turns: one pass, four counters
+        int agree[4] = {0, 0, 0, 0};
+        for (int m = 0; m < V; m++) {
+            const unsigned a = tile_u8(P.dec, P.out_rows, s, j0 - 1 - m);
+            const unsigned b = tile_u8(P.dec, P.out_rows, s - 1, jp - 1 - m);
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++) agree[r4] += rot_quadrant(a, r4) == b;
         }
+        int best = -1;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++)
+            if (agree[r4] > best) { best = agree[r4]; rot = r4; }
     }
     if (j0 > j1) j0 = j1;
     P.j0[s] = j0;
@@ -139,13 +141,16 @@ __global__ __launch_bounds__(1024) void seg_offsets_k(SegParams P)
     for (int s = lo; s < hi; s++) { c += P.j1[s] - P.j0[s]; r += P.rot[s]; }
     cnt[t] = c; rsum[t] = r;
     __syncthreads();
-    if (t == 0) {
-        long long a = 0; int b = 0;
-        for (int i = 0; i < 1024; i++) { const long long c0 = cnt[i]; const int r0 = rsum[i]; cnt[i] = a; rsum[i] = b; a += c0; b += r0; }
-        P.off[P.S] = a;
+    // exclusive scan of the 1024 partial sums (Hillis-Steele, inclusive, then shifted by one)
+    for (int d = 1; d < 1024; d <<= 1) {
+        const long long c1 = t >= d ? cnt[t - d] : 0;
+        const int r1 = t >= d ? rsum[t - d] : 0;
+        __syncthreads();
+        cnt[t] += c1; rsum[t] += r1;
+        __syncthreads();
     }
-    __syncthreads();
-    long long a = cnt[t]; int b = rsum[t];
+    if (t == 1023) P.off[P.S] = cnt[1023];
+    long long a = cnt[t] - c; int b = rsum[t] - r;         // exclusive: the sums in front of this thread's slice
     for (int s = lo; s < hi; s++) {
         b += P.rot[s];                       // window s is turned by the sum of the relative turns up to s
         P.off[s] = a;
