@@ -165,8 +165,28 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
                 if (counts) { s_re += are[o]; s_im += aim[o]; cnt++; }
                 if (dst && n < P.rows) put(dst + (size_t)n * 64, valid ? are[o] * scale : 0.0,
                                            valid ? aim[o] * scale : 0.0);
-                if (feed && n >= feed_lo && n < feed_hi) put(feed + (ptrdiff_t)n * 64, valid ? are[o] * scale : 0.0,
-                                                             valid ? aim[o] * scale : 0.0);
+            }
+            if (P.feed_lead) {
+                // a branch per output costs more than the store: groups wholly inside every lane's
+                // range (the usual case, ranges and groups are multiples of OG) store unconditionally
+                const int n_a = n0 + o0, n_z = n_a + OG - 1;
+                const bool in_all = feed && n_a >= feed_lo && n_z < feed_hi;
+                const bool in_any = feed && n_z >= feed_lo && n_a < feed_hi;
+                if (__all(in_all)) {
+#pragma unroll
+                    for (int o = 0; o < OG; o++) {
+                        const bool valid = n_a + o < len;
+                        put(feed + (ptrdiff_t)(n_a + o) * 64, valid ? are[o] * scale : 0.0, valid ? aim[o] * scale : 0.0);
+                    }
+                } else if (__any(in_any)) {
+#pragma unroll
+                    for (int o = 0; o < OG; o++) {
+                        const int n = n_a + o;
+                        const bool valid = n < len;
+                        if (feed && n >= feed_lo && n < feed_hi)
+                            put(feed + (ptrdiff_t)n * 64, valid ? are[o] * scale : 0.0, valid ? aim[o] * scale : 0.0);
+                    }
+                }
             }
         }
     }
