@@ -73,7 +73,38 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
     // W <= 64 * KS (launch_fir_tile_t), so a wave covers a row in KS steps; all 16 * KS loads of a wave are
     // issued before the first LDS write (each wave would otherwise pay the HBM latency once per load).
     const int x0 = n0 + P.start - (M - 1);
-    {
+    // Interior chunks of full tiles need no bounds logic at all (it is half of the kernel's instructions
+    // otherwise): every staged index of all 64 rows lies inside its burst, or inside the stream (window
+    // starts do not decrease with the window number).
+    bool fast = false;
+    if (tile * 64 + 63 < P.B) {
+        if (P.starts) fast = P.starts[tile * 64] + x0 >= 0 && P.starts[tile * 64 + 63] + x0 + W <= P.n_total;
+        else fast = !P.lens && x0 >= 0 && x0 + W <= P.len_all;
+    }
+    if (fast) {
+        IN v[16][KS];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int b = tile * 64 + w * 16 + q;
+            const IN *src = P.starts ? (const IN *)P.src + (P.starts[b] + x0) : (const IN *)P.src + ((int64_t)b * P.ld + x0);
+#pragma unroll
+            for (int k = 0; k < KS; k++) {
+                int i = lane + 64 * k;
+                if (i > W - 1) i = W - 1;              // idle lanes of the last step re-read the row's end
+                v[q][k] = src[i];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            ST *row = xs + (size_t)(w * 16 + q) * stride;
+#pragma unroll
+            for (int k = 0; k < KS; k++) {
+                const int i = lane + 64 * k;
+                if (64 * (k + 1) <= W) row[i] = to_stage(v[q][k], isc);
+                else if (i < W) row[i] = to_stage(v[q][k], isc);
+            }
+        }
+    } else {
         IN v[16][KS];
         bool ok[16][KS];
 #pragma unroll
@@ -130,13 +161,14 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
     }
     const int feed_hi = feed_lo + P.skip_rows;
     const int per_wave = CH / 4;
-    double s_re = 0.0, s_im = 0.0;      // sums of this lane's valid outputs
+    // statistics of this lane's counted outputs in one pass: sums of (y - c) and |y - c|^2 around the
+    // first counted output c (a sample of the data, so the usual cancellation of the sum-of-squares
+    // form cannot occur, whatever the signal's offset)
+    double s_re = 0.0, s_im = 0.0, s_sq = 0.0, c_re = 0.0, c_im = 0.0;
     int cnt = 0;
-    // keep the outputs for the second (M2) pass in registers: per_wave <= 32
-    double yre[32], yim[32];
-#pragma unroll
-    for (int g = 0; g < 32 / OG; g++) {
-        if (g * OG < per_wave) {
+#pragma unroll 1
+    for (int g = 0; g * OG < per_wave; g++) {
+        {
             const int o0 = w * per_wave + g * OG;
             double are[OG], aim[OG];
 #pragma unroll
@@ -160,9 +192,12 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
                 const int n = n0 + o0 + o;
                 const bool valid = n < len;
                 const bool counts = valid && n >= st_lo && n < st_hi;
-                yre[g * OG + o] = counts ? are[o] : 0.0;
-                yim[g * OG + o] = counts ? aim[o] : 0.0;
-                if (counts) { s_re += are[o]; s_im += aim[o]; cnt++; }
+                if (counts) {
+                    if (cnt == 0) { c_re = are[o]; c_im = aim[o]; }
+                    const double dr = are[o] - c_re, di = aim[o] - c_im;
+                    s_re += dr; s_im += di; s_sq += dr * dr + di * di;
+                    cnt++;
+                }
                 if (dst && n < P.rows) put(dst + (size_t)n * 64, valid ? are[o] * scale : 0.0,
                                            valid ? aim[o] * scale : 0.0);
             }
@@ -191,36 +226,30 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
         }
     }
     if (!P.stats) return;
-    // ---- per (burst, chunk) statistics: exact two-pass inside the chunk ----------
+    // ---- per (burst, chunk) statistics: each wave's (n, mean, M2), merged over the four waves (Chan) ----
     __syncthreads();                    // every wave is done with xs: reuse it as scratch
-    red[(w * 64 + lane) * 4 + 0] = s_re;
-    red[(w * 64 + lane) * 4 + 1] = s_im;
-    red[(w * 64 + lane) * 4 + 2] = (double)cnt;
-    __syncthreads();
-    double t_re = 0.0, t_im = 0.0, t_n = 0.0;
-    for (int q = 0; q < 4; q++) {
-        t_re += red[(q * 64 + lane) * 4 + 0];
-        t_im += red[(q * 64 + lane) * 4 + 1];
-        t_n += red[(q * 64 + lane) * 4 + 2];
+    {
+        const double n = (double)cnt;
+        const double mr = cnt ? s_re / n : 0.0, mi = cnt ? s_im / n : 0.0;     // mean of (y - c)
+        red[(w * 64 + lane) * 4 + 0] = n;
+        red[(w * 64 + lane) * 4 + 1] = c_re + mr;
+        red[(w * 64 + lane) * 4 + 2] = c_im + mi;
+        red[(w * 64 + lane) * 4 + 3] = cnt ? s_sq - n * (mr * mr + mi * mi) : 0.0;
     }
-    const double m_re = t_n > 0.0 ? t_re / t_n : 0.0, m_im = t_n > 0.0 ? t_im / t_n : 0.0;
-    double m2 = 0.0;
-#pragma unroll
-    for (int j = 0; j < 32; j++) {
-        if (j < per_wave) {
-            const int n = n0 + w * per_wave + j;
-            if (n < len && n >= st_lo && n < st_hi) {
-                const double dr = yre[j] - m_re, di = yim[j] - m_im;
-                m2 += dr * dr + di * di;
-            }
-        }
-    }
-    __syncthreads();
-    red[(w * 64 + lane) * 4 + 3] = m2;
     __syncthreads();
     if (w == 0 && b < P.B) {
-        double t_m2 = 0.0;
-        for (int q = 0; q < 4; q++) t_m2 += red[(q * 64 + lane) * 4 + 3];
+        double t_n = 0.0, m_re = 0.0, m_im = 0.0, t_m2 = 0.0;
+        for (int q = 0; q < 4; q++) {
+            const double *r = red + (q * 64 + lane) * 4;
+            const double nb = r[0];
+            if (nb <= 0.0) continue;
+            const double nn = t_n + nb, dr = r[1] - m_re, di = r[2] - m_im;
+            t_m2 += r[3] + (dr * dr + di * di) * (t_n * nb / nn);
+            m_re += dr * (nb / nn);
+            m_im += di * (nb / nn);
+            t_n = nn;
+        }
+        if (t_m2 < 0.0) t_m2 = 0.0;
         double *st = P.stats + ((size_t)b * P.nchunk + chunk) * 4;
         st[0] = t_n; st[1] = m_re; st[2] = m_im; st[3] = t_m2;
     }
@@ -456,15 +485,13 @@ hipError_t launch_fir_tile_t(const FirParams &P, hipStream_t s)
     if (xs_bytes < (size_t)4 * 64 * 4 * 8) xs_bytes = (size_t)4 * 64 * 4 * 8;
     size_t lds = (size_t)((P.M + 7) & ~7) * 8 + xs_bytes;
     if (P.W > 192) return hipErrorInvalidValue;
+    void (*k)(FirParams) = P.W > 128 ? fir_tile_kernel<IN, OUT, OG, 3> : fir_tile_kernel<IN, OUT, OG, 2>;
     if (P.W > 128) {
         // more than 64 KB of dynamic LDS has to be asked for (per device: cheap, so every launch)
-        hipError_t e = hipFuncSetAttribute((const void *)fir_tile_kernel<IN, OUT, OG, 3>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((fir_tile_kernel<IN, OUT, OG, 3>), dim3(nchunk, ntiles), dim3(256), lds, s, P);
-    } else {
-        hipLaunchKernelGGL((fir_tile_kernel<IN, OUT, OG, 2>), dim3(nchunk, ntiles), dim3(256), lds, s, P);
     }
+    hipLaunchKernelGGL(k, dim3(nchunk, ntiles), dim3(256), lds, s, P);
     return hipGetLastError();
 }
 

@@ -69,6 +69,30 @@ def test_fir_batch_ragged_vs_oracle(ctx, oracle):
             assert np.all(Y[b, L:] == 0)
 
 
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_fir_batch_full_tiles_vs_oracle(ctx, oracle, dtype):
+    """Full tiles of equal-length bursts: interior chunks take the staging path without bounds logic,
+    the first and last chunks (and the 6 bursts of the third tile) the general one; a DC offset 50
+    times the spread checks the one-pass statistics."""
+    import dsp_amd
+    rng = np.random.default_rng(11)
+    B, N = 134, 1500
+    X = (rng.standard_normal((B, N)) + 1j * rng.standard_normal((B, N))).astype(dtype)
+    X[5] += 50.0 - 20.0j
+    for taps in (dsp_amd.rrc_filter(4, 10, 0.35), rng.standard_normal(17), rng.standard_normal(75)):
+        Y, std = dsp_amd.fir_batch(X, taps, normalize=True, want_std=True)
+        for b in list(range(0, B, 7)) + [5, 63, 64, 127, 128, B - 1]:
+            yo = oracle.convolve_same(X[b], taps)
+            so = oracle.np_std(yo)
+            assert abs(std[b] - so) / so < 1e-13, b
+            ref = (yo * (1.0 / so)).astype(dtype)
+            if dtype == np.complex64:
+                ulp = np.spacing(np.maximum(np.abs(ref.real), np.abs(ref.imag)))
+                assert np.max(np.abs(Y[b] - ref) / ulp) <= 1.0, b
+            else:
+                assert np.max(np.abs(Y[b] - ref)) < 1e-12 * np.max(np.abs(ref)), b
+
+
 def test_rrc_cascade_long_filter(ctx):
     """hw1/test_rrc_cascade.py: 1002-tap filter, full convolution cropped by len(h)//2 (the long
     filter takes the direct-form kernel)."""
