@@ -89,6 +89,7 @@ struct FirParams {
     double *stats;            // [B][nchunk][4] partial statistics, or NULL
     int nchunk, CH, W, stride;
     int skip_rows;            // tiles > 0 skip the chunks that end at or before this output row (0 = none)
+    int waves;                // waves per workgroup: 0 = auto (8 where the chunk divides), 4 = always 4
     int feed_lead;            // 1: every window also stores its rows [shift, shift + skip_rows) as rows [0, skip_rows)
                               //    of its successor (shift = starts[b+1] - starts[b]; successors in tiles > 0 only)
 };

@@ -34,8 +34,9 @@ __device__ __forceinline__ d2v to_stage(d2v v, float) { return v; }
 __device__ __forceinline__ void put(f2v *p, double re, double im) { *p = f2v{(float)re, (float)im}; }
 __device__ __forceinline__ void put(d2v *p, double re, double im) { *p = d2v{re, im}; }
 
-template <typename IN, typename OUT, int OG, int KS>
-__global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
+// NW waves per workgroup (4 or 8): each stages 64 / NW rows and computes CH / NW outputs per lane
+template <typename IN, typename OUT, int OG, int KS, int NW>
+__global__ __launch_bounds__(64 * NW) void fir_tile_kernel(FirParams P)
 {
     typedef typename Stage<IN>::T ST;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
         const int idle0 = P.B - tile * 64;
         if (P.feed_lead && P.dst && idle0 < 64) {
             OUT *d = (OUT *)P.dst + (size_t)tile * P.rows * 64;
-            for (int i = threadIdx.x; i < CH * 64; i += 256) {
+            for (int i = threadIdx.x; i < CH * 64; i += 64 * NW) {
                 const int r = n0 + (i >> 6), l = i & 63;
                 if (l >= idle0 && r < P.rows) put(d + (size_t)r * 64 + l, 0.0, 0.0);
             }
@@ -66,9 +67,10 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
         return;
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    constexpr int RQ = 64 / NW;                        // rows a wave stages
     const float isc = P.in_scale ? *P.in_scale : 1.0f;
 
-    for (int i = threadIdx.x; i < m8; i += 256) hrev[i] = i < M ? P.h[M - 1 - i] : 0.0;
+    for (int i = threadIdx.x; i < m8; i += 64 * NW) hrev[i] = i < M ? P.h[M - 1 - i] : 0.0;
     // stage the input windows: xs[bb][i] = x[b][n0 + start - (M-1) + i], zero outside the burst.
     // W <= 64 * KS (launch_fir_tile_t), so a wave covers a row in KS steps; all 16 * KS loads of a wave are
     // issued before the first LDS write (each wave would otherwise pay the HBM latency once per load).
@@ -82,10 +84,10 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
         else fast = !P.lens && x0 >= 0 && x0 + W <= P.len_all;
     }
     if (fast) {
-        IN v[16][KS];
+        IN v[RQ][KS];
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int b = tile * 64 + w * 16 + q;
+        for (int q = 0; q < RQ; q++) {
+            const int b = tile * 64 + w * RQ + q;
             const IN *src = P.starts ? (const IN *)P.src + (P.starts[b] + x0) : (const IN *)P.src + ((int64_t)b * P.ld + x0);
 #pragma unroll
             for (int k = 0; k < KS; k++) {
@@ -95,8 +97,8 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
             }
         }
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            ST *row = xs + (size_t)(w * 16 + q) * stride;
+        for (int q = 0; q < RQ; q++) {
+            ST *row = xs + (size_t)(w * RQ + q) * stride;
 #pragma unroll
             for (int k = 0; k < KS; k++) {
                 const int i = lane + 64 * k;
@@ -105,11 +107,11 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
             }
         }
     } else {
-        IN v[16][KS];
-        bool ok[16][KS];
+        IN v[RQ][KS];
+        bool ok[RQ][KS];
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int b = tile * 64 + w * 16 + q;
+        for (int q = 0; q < RQ; q++) {
+            const int b = tile * 64 + w * RQ + q;
             const bool live = b < P.B;
             if (P.starts) {         // window of one long stream: true neighbours across the window edges
                 const int64_t st = live ? P.starts[b] : 0;
@@ -133,11 +135,11 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
             }
         }
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
+        for (int q = 0; q < RQ; q++) {
 #pragma unroll
             for (int k = 0; k < KS; k++) {
                 const int i = lane + 64 * k;
-                if (i < W) xs[(size_t)(w * 16 + q) * stride + i] = ok[q][k] ? to_stage(v[q][k], isc) : ST{0, 0};
+                if (i < W) xs[(size_t)(w * RQ + q) * stride + i] = ok[q][k] ? to_stage(v[q][k], isc) : ST{0, 0};
             }
         }
     }
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
         feed = (OUT *)P.dst + (size_t)((b + 1) >> 6) * P.rows * 64 + ((b + 1) & 63) - (ptrdiff_t)feed_lo * 64;
     }
     const int feed_hi = feed_lo + P.skip_rows;
-    const int per_wave = CH / 4;
+    const int per_wave = CH / NW;
     // statistics of this lane's counted outputs in one pass: sums of (y - c) and |y - c|^2 around the
     // first counted output c (a sample of the data, so the usual cancellation of the sum-of-squares
     // form cannot occur, whatever the signal's offset)
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(FirParams P)
     __syncthreads();
     if (w == 0 && b < P.B) {
         double t_n = 0.0, m_re = 0.0, m_im = 0.0, t_m2 = 0.0;
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < NW; q++) {
             const double *r = red + (q * 64 + lane) * 4;
             const double nb = r[0];
             if (nb <= 0.0) continue;
@@ -477,21 +479,27 @@ __global__ void iq_i16_convert_kernel(const s2v *__restrict__ raw, int64_t n, co
         out[i] = f2v{(float)raw[i].x * s, (float)raw[i].y * s};
 }
 
-template <typename IN, typename OUT, int OG>
+template <typename IN, typename OUT, int OG, int OG8>
 hipError_t launch_fir_tile_t(const FirParams &P, hipStream_t s)
 {
     const int nchunk = P.nchunk, ntiles = (P.B + 63) / 64;
     size_t xs_bytes = (size_t)64 * P.stride * sizeof(typename Stage<IN>::T);
-    if (xs_bytes < (size_t)4 * 64 * 4 * 8) xs_bytes = (size_t)4 * 64 * 4 * 8;
+    if (xs_bytes < (size_t)8 * 64 * 4 * 8) xs_bytes = (size_t)8 * 64 * 4 * 8;      // the statistics scratch: [NW][64][4] doubles
     size_t lds = (size_t)((P.M + 7) & ~7) * 8 + xs_bytes;
     if (P.W > 192) return hipErrorInvalidValue;
-    void (*k)(FirParams) = P.W > 128 ? fir_tile_kernel<IN, OUT, OG, 3> : fir_tile_kernel<IN, OUT, OG, 2>;
+    // 8 waves per workgroup (two workgroups per CU = 4 waves per SIMD: the SIMD issues an fp64 instruction
+    // every 2.7 ticks instead of 3.5 at 2 waves; 4.18 -> 3.66 ms per pass) when each wave's share of the
+    // chunk is a whole number of OG8-output blocks; 4 waves with OG-output blocks otherwise
+    const bool w8 = OG8 > 0 && P.waves != 4 && P.CH >= 8 * OG8 && (P.CH / 8) % OG8 == 0;
+    void (*k)(FirParams);
+    if (w8) k = P.W > 128 ? fir_tile_kernel<IN, OUT, (OG8 > 0 ? OG8 : OG), 3, 8> : fir_tile_kernel<IN, OUT, (OG8 > 0 ? OG8 : OG), 2, 8>;
+    else k = P.W > 128 ? fir_tile_kernel<IN, OUT, OG, 3, 4> : fir_tile_kernel<IN, OUT, OG, 2, 4>;
     if (P.W > 128) {
         // more than 64 KB of dynamic LDS has to be asked for (per device: cheap, so every launch)
         hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k, dim3(nchunk, ntiles), dim3(256), lds, s, P);
+    hipLaunchKernelGGL(k, dim3(nchunk, ntiles), dim3(w8 ? 512 : 256), lds, s, P);
     return hipGetLastError();
 }
 
@@ -521,9 +529,9 @@ bool fir_plan(int in_kind, int M, int n_out, FirParams &P)
 hipError_t launch_fir_tile(const FirParams &P, int in_kind, hipStream_t s)
 {
     switch (in_kind) {
-        case DSP_IN_I16: return launch_fir_tile_t<s2v, f2v, 8>(P, s);
-        case DSP_IN_C64: return launch_fir_tile_t<f2v, f2v, 8>(P, s);
-        case DSP_IN_C128: return launch_fir_tile_t<d2v, d2v, 4>(P, s);
+        case DSP_IN_I16: return launch_fir_tile_t<s2v, f2v, 8, 6>(P, s);
+        case DSP_IN_C64: return launch_fir_tile_t<f2v, f2v, 8, 6>(P, s);
+        case DSP_IN_C128: return launch_fir_tile_t<d2v, d2v, 4, 0>(P, s);
     }
     return hipErrorInvalidValue;
 }
