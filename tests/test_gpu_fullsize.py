@@ -88,3 +88,54 @@ def test_device_generator_statistics(ctx):
     tau, f, phi = device_params(SEED, 7)
     assert -0.5 <= tau <= 0.5 and abs(f) <= 5e-4 and 0 <= phi <= 2 * np.pi
     pipe.close()
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_spare_wave_launch_bit_identical(ctx, oracle, variant):
+    """Two workgroups per CU (257..512 tiles): the two-wave kernel is launched with an idle middle
+    wave.  Same bits as the plain two-wave launch for every burst and output, both timing-loop variants,
+    and oracle parity on sampled bursts (gardner2)."""
+    from dsp_amd.pipeline import BurstPipeline
+    B = 20032                                   # 313 tiles
+    pipe = BurstPipeline(ctx, B, 512, 4, variant=variant)
+    pipe.generate(SEED, b0=0)
+    pipe.matched_filter(free_raw=True)
+    got = {}
+    try:
+        for sw in (0, -1):
+            ctx.set_option("spare_wave", sw)
+            pipe.run()
+            got[sw] = {k: pipe.fetch(k, 0, B) for k in ("dec", "mu", "freq", "rec")}
+            got[sw]["n"] = pipe.n_out().copy()
+    finally:
+        ctx.set_option("spare_wave", -1)
+    assert np.array_equal(got[0]["n"], got[-1]["n"])
+    for k in ("dec", "mu", "freq", "rec"):
+        assert np.array_equal(got[0][k], got[-1][k]), k
+    if variant == 0:
+        for b in (0, 63, 64, 9999, B - 1):
+            t0 = b // 64 * 64
+            X = pipe.fetch_input(t0, t0 + 64)
+            o = oracle.sync_chain_c64(X[b - t0])
+            assert np.array_equal(got[-1]["dec"][b, :o["n"]], o["dec"])
+    pipe.close()
+
+
+def test_spare_wave_complex128_host_path(ctx):
+    """The complex128 form of the kernel through the host-pointer entry point at two workgroups per CU."""
+    import dsp_amd
+    rng = np.random.default_rng(5)
+    B, N = 20032, 256
+    q = rng.integers(0, 4, (B, N // 4))
+    sym = ((1 - 2 * (q & 1)) + 1j * (1 - 2 * (q >> 1))) / np.sqrt(2)
+    x = np.repeat(sym, 4, axis=1) + 0.05 * (rng.standard_normal((B, N)) + 1j * rng.standard_normal((B, N)))
+    h = dsp_amd.rrc_filter(4, 10, 0.35)
+    out = {}
+    try:
+        for sw in (0, -1):
+            ctx.set_option("spare_wave", sw)
+            out[sw] = dsp_amd.rx_chain_batch(x, h, 4, 0.007, 0.0, 0.03, 1, outputs=("sig", "dec", "mu", "freq"), ctx=ctx)
+    finally:
+        ctx.set_option("spare_wave", -1)
+    for k in ("sig", "dec", "mu", "freq", "n_out"):
+        assert np.array_equal(out[0][k], out[-1][k]), k
