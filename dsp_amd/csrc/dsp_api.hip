@@ -20,7 +20,8 @@ struct dsp_ctx {
     int split;          // -1 auto / 1: two waves per tile where applicable; 0: one wave per tile
     int queue_block;    // split kernel: symbols per hand-off block, 0 = automatic
     int lead_copy;      // segment-parallel mode, warm-up rows: 0 = the filter's second store, 1 = seg_lead_copy_k, 2 = filtered per window
-    int spare_wave;     // split kernel: 3 waves per tile with the middle one idle: -1 auto, 0 never, 1 always
+    int spare_wave;     // split kernel, idle waves for SIMD balance: -1 auto, 0 never, 1 three waves, 2 four waves + CU tickets
+    unsigned *cu_tickets;   // [4096] per-CU workgroup counters for the four-wave launch
     int prio_period;    // split kernel: priority rotation period in DMA blocks (power of two), 0 = off
     // grow-only device scratch kept between calls of the segment-parallel mode (its window tiles are
     // gigabytes: hipMalloc / hipFree per call cost milliseconds); released by dsp_trim / dsp_destroy
@@ -136,6 +137,9 @@ int dsp_create(int device_id, dsp_ctx **out)
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    c->cu_tickets = nullptr;
+    if (e == hipSuccess) e = hipMalloc((void **)&c->cu_tickets, 4096 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(c->cu_tickets, 0, 4096 * sizeof(unsigned));
     if (e != hipSuccess) {
         delete c;
         return fail(DSP_E_HIP, "context creation failed: %s", hipGetErrorString(e));
@@ -150,6 +154,7 @@ void dsp_destroy(dsp_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     ctx_trim(c);
+    if (c->cu_tickets) (void)hipFree(c->cu_tickets);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -203,7 +208,7 @@ int dsp_set_option(dsp_ctx *c, const char *name, int64_t value)
         if (value < 0 || value > 2) return fail(DSP_E_ARG, "lead_copy must be 0, 1 or 2");
         c->lead_copy = (int)value;
     } else if (!strcmp(name, "spare_wave")) {
-        if (value < -1 || value > 1) return fail(DSP_E_ARG, "spare_wave must be -1 (auto), 0 or 1");
+        if (value < -1 || value > 2) return fail(DSP_E_ARG, "spare_wave must be -1 (auto), 0, 1 or 2");
         c->spare_wave = (int)value;
     } else if (!strcmp(name, "prio_period")) {
         if (value < 0 || value > 4096 || (value & (value - 1))) return fail(DSP_E_ARG, "prio_period must be 0 or a power of two");
@@ -433,7 +438,7 @@ int dsp_sync_tiles_dev(dsp_ctx *c, const dsp_sync_args *a)
     P.TQ = 0;
     if (split) {
         // queue block: as many symbols as the double buffer can hold inside the budget
-        const size_t room = lds + queue_min > budget ? budget_all : budget;
+        const size_t room = (lds + queue_min > budget ? budget_all : budget) - 32;
         int TQ = c->queue_block;
         if (TQ == 0) {
             TQ = 1;
@@ -446,8 +451,9 @@ int dsp_sync_tiles_dev(dsp_ctx *c, const dsp_sync_args *a)
         // two 2-wave workgroups per CU land on three SIMDs (sync_kernels.hip); the idle middle wave
         // spreads them over four.  Measured: 512 tiles 1.57 -> 1.30 ms; no gain at one workgroup per
         // CU, 3 % slower at three or four, and at eight the spare waves cost occupancy
-        P.spare_wave = c->spare_wave >= 0 ? c->spare_wave : (per_cu == 2 ? 1 : 0);
-        lds += (size_t)2 * TQ * 64 * 17 + 16;
+        P.spare_wave = c->spare_wave >= 0 ? c->spare_wave : (per_cu == 2 ? 2 : 0);
+        P.cu_tickets = c->cu_tickets;
+        lds += (size_t)2 * TQ * 64 * 17 + 16 + 32;       // + the four-wave launch's five selection words
     }
     if (c->lds_pad >= 0) lds += (size_t)c->lds_pad;
     else if (budget > lds) lds = budget;

@@ -43,7 +43,8 @@ struct SyncParams {
     // LDS ring schedule (host-computed, see sync_plan())
     int use_ring, ring_rows, T, C, nwait;
     int TQ;                   // > 0: split kernel, queue block length (iterations)
-    int spare_wave;           // split kernel: 1 = launch 3 waves per tile, the middle one idle (SIMD balance)
+    int spare_wave;           // split kernel: 1 = 3 waves per tile, the middle one idle; 2 = 4 waves, two chosen by CU ticket
+    unsigned *cu_tickets;     // [4096] per-CU workgroup counters (spare_wave == 2)
     int prio_period;          // split kernel: rotate the wave priority every this many DMA blocks (power of 2, 0 = off)
 #ifdef DSP_TRACE
     unsigned long long *trace; // diagnostic build only: [tile][role][20] = start, end (s_memtime), HW_ID, XCC_ID, 16 segment sums

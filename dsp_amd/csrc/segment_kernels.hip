@@ -194,40 +194,40 @@ __global__ __launch_bounds__(256) void seg_lead_copy_k(float2 *__restrict__ tile
 // strobes x[p + k sps], k < n_sym, carry the most energy -- the spectral line of |x|^2 at the symbol
 // rate (Oerder-Meyr) read on the sample grid, at most half a sample from the lock point.  Lane =
 // window over the tiled filter output; sums in float64, in k order (the oracle adds in the same order).
-__global__ __launch_bounds__(64) void seg_phase_k(const float2 *__restrict__ tiles, int rows,
-                                                  const int *__restrict__ lens, int S, int sps, int n_sym,
-                                                  double *__restrict__ mu0)
+__global__ __launch_bounds__(512) void seg_phase_k(const float2 *__restrict__ tiles, int rows,
+                                                   const int *__restrict__ lens, int S, int sps, int n_sym,
+                                                   double *__restrict__ mu0)
 {
-    const int lane = threadIdx.x, tile = blockIdx.x, w = tile * 64 + lane;
-    if (w >= S) return;
-    const int len = lens[w];
+    // one wave per sampling phase (sps <= 8: the workgroup has sps waves), each adding its phase's
+    // strobes in k order, 8 loads in flight; wave 0 then takes the first maximum over the phases
+    __shared__ double e[8][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, tile = blockIdx.x, w = tile * 64 + lane;
+    const int len = w < S ? lens[w] : 0;
     const int ns = n_sym < len / sps ? n_sym : len / sps;
     const float2 *base = tiles + (size_t)tile * rows * 64 + lane;
-    double best = -1.0;
-    int arg = 0;
     if (sps <= 8) {
-        // one pass, 4 symbols x sps rows loaded before they are added (the adds stay in k order)
-        double acc[8];
+        double acc = 0.0;
+        for (int k0 = 0; k0 < ns; k0 += 8) {
+            float2 v[8];
 #pragma unroll
-        for (int p = 0; p < 8; p++) acc[p] = 0.0;
-        for (int k0 = 0; k0 < ns; k0 += 4) {
-            float2 v[4][8];
+            for (int kk = 0; kk < 8; kk++)
+                v[kk] = k0 + kk < ns ? base[(size_t)((k0 + kk) * sps + wv) * 64] : float2{0.f, 0.f};
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++)
-#pragma unroll
-                for (int p = 0; p < 8; p++)
-                    v[kk][p] = (p < sps && k0 + kk < ns) ? base[(size_t)((k0 + kk) * sps + p) * 64] : float2{0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++)
-#pragma unroll
-                for (int p = 0; p < 8; p++)
-                    if (p < sps && k0 + kk < ns)
-                        acc[p] += (double)v[kk][p].x * (double)v[kk][p].x + (double)v[kk][p].y * (double)v[kk][p].y;
+            for (int kk = 0; kk < 8; kk++)
+                if (k0 + kk < ns) acc += (double)v[kk].x * (double)v[kk].x + (double)v[kk].y * (double)v[kk].y;
         }
-#pragma unroll
-        for (int p = 0; p < 8; p++)
-            if (p < sps && acc[p] > best) { best = acc[p]; arg = p; }
-    } else {
+        e[wv][lane] = acc;
+        __syncthreads();
+        if (wv == 0 && w < S) {
+            double best = -1.0;
+            int arg = 0;
+            for (int p = 0; p < sps; p++)
+                if (e[p][lane] > best) { best = e[p][lane]; arg = p; }
+            mu0[w] = (double)arg;
+        }
+    } else if (wv == 0 && w < S) {
+        double best = -1.0;
+        int arg = 0;
         for (int p = 0; p < sps; p++) {
             double acc = 0.0;
             for (int k = 0; k < ns; k++) {
@@ -236,8 +236,8 @@ __global__ __launch_bounds__(64) void seg_phase_k(const float2 *__restrict__ til
             }
             if (acc > best) { best = acc; arg = p; }
         }
+        mu0[w] = (double)arg;
     }
-    mu0[w] = (double)arg;
 }
 
 // 64 windows x 64 rows per workgroup through LDS so that both sides are contiguous
@@ -356,8 +356,8 @@ hipError_t launch_seg_lead_copy(void *tiles, int rows, const int64_t *starts, in
 hipError_t launch_seg_phase(const void *tiles, int rows, const int *lens, int S, int sps, int n_sym, double *mu0,
                             hipStream_t s)
 {
-    hipLaunchKernelGGL(seg_phase_k, dim3((S + 63) / 64), dim3(64), 0, s, (const float2 *)tiles, rows, lens, S, sps,
-                       n_sym, mu0);
+    hipLaunchKernelGGL(seg_phase_k, dim3((S + 63) / 64), dim3(sps <= 8 ? 64 * sps : 64), 0, s, (const float2 *)tiles, rows,
+                       lens, S, sps, n_sym, mu0);
     return hipGetLastError();
 }
 

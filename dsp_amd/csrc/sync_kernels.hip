@@ -565,7 +565,7 @@ __device__ __forceinline__ unsigned wave_slot()
 //   Block qb: wave 0 fills queue[qb&1], s_barrier; wave 1 drains it while wave 0
 //   fills the other half.  Every block both waves execute exactly one barrier.
 template <typename IN, int VARIANT, bool SC>
-__global__ __launch_bounds__(192) void sync_split_kernel(SyncParams P)
+__global__ __launch_bounds__(256) void sync_split_kernel(SyncParams P)
 {
     typedef typename InT<IN>::OS OS;
     typedef typename InT<IN>::OC OC;
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(192) void sync_split_kernel(SyncParams P)
     // at every later s_barrier of its workgroup.
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (blockDim.x == 192 && wv == 1) return;
-    const int role = wv ? 1 : 0;                                         // 0 = timing, 1 = FLL
+    int role = wv ? 1 : 0;                                               // 0 = timing, 1 = FLL
     const int tile = blockIdx.x;
     const int b = tile * 64 + lane;
     const bool lane_ok = b < P.B;
@@ -598,6 +598,33 @@ __global__ __launch_bounds__(192) void sync_split_kernel(SyncParams P)
     typedef __attribute__((address_space(3))) int lds_int;
     lds_int *q_more = (lds_int *)(q_flag + (size_t)2 * TQ * 64);               // [2]
     constexpr int ROFF = (VARIANT == DSP_VARIANT_TED) ? 0 : 1;      // FLL row of queue entry `it` = it + ROFF
+    if (blockDim.x == 256) {
+        // Four waves: the dispatcher puts them on the CU's four SIMDs (order 0, 2, 1, 3 from wherever
+        // it stands).  The workgroup draws a ticket from its CU's counter; the two waves on SIMD pair
+        // {0,1} (even ticket) or {2,3} (odd) become the timing and the FLL wave, the other two leave.
+        // Two workgroups on a CU draw consecutive tickets, so their live waves never share a SIMD,
+        // whatever kernels ran before (the 192-thread launch relies on the dispatcher's position).
+        lds_int *sel = q_more + 2;                                  // [0..3] SIMD of wave i, [4] ticket parity
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if (lane == 0) sel[wv] = (int)((hw >> 4) & 3u);
+        if (threadIdx.x == 0) {
+            const unsigned cu = ((xcc & 15u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
+            sel[4] = (int)(atomicAdd(P.cu_tickets + cu, 1u) & 1u);
+        }
+        __syncthreads();
+        const int t = sel[4];
+        int first = -1, second = -1, n = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if ((sel[i] >> 1) == t) { if (n == 0) first = i; else if (n == 1) second = i; n++; }
+        if (n != 2) { first = 0; second = 2; }                      // not one wave per SIMD: any two will do
+        first = __builtin_amdgcn_readfirstlane(first);
+        second = __builtin_amdgcn_readfirstlane(second);
+        if (wv != first && wv != second) return;
+        role = wv == first ? 0 : 1;
+    }
     const unsigned slot = wave_slot();
     int prio_n = P.prio_period, prio_c = 1, prio_ph = 0;
 #ifdef DSP_TRACE
@@ -834,7 +861,7 @@ static hipError_t launch_in(const SyncParams &P, int variant, bool fll, size_t l
             hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(k, dim3(ntiles), dim3(P.spare_wave ? 192 : 128), lds, s, P);
+        hipLaunchKernelGGL(k, dim3(ntiles), dim3(P.spare_wave == 2 && P.cu_tickets ? 256 : P.spare_wave ? 192 : 128), lds, s, P);
         return hipGetLastError();
     }
     switch (variant) {

@@ -52,8 +52,8 @@ int dsp_synchronize(dsp_ctx *ctx);
 int dsp_set_option(dsp_ctx *ctx, const char *name, int64_t value); /* tuning knobs: "ring_rows" (LDS ring rows, 0 auto),
    "lds_pad", "split" (-1 auto / 0 one wave per tile / 1 two), "queue_block" (hand-off block, 0 auto),
    "prio_period" (rotate wave priorities every N DMA blocks, 0 off), "spare_wave" (two-wave kernel
-   launched with an idle middle wave so that two workgroups on a CU use four SIMDs: -1 auto = at two
-   workgroups per CU, 0 never, 1 always), "lead_copy" (segment-parallel mode, a window's warm-up rows: 0 = stored
+   launched with idle waves so that two workgroups on a CU use four SIMDs: -1 auto = at two workgroups
+   per CU, 0 never, 1 one idle wave, 2 two idle waves chosen by a per-CU ticket), "lead_copy" (segment-parallel mode, a window's warm-up rows: 0 = stored
    by the predecessor's filter workgroup, default; 1 = copied by a kernel after the filter; 2 = filtered again) */
 
 /* ---- device memory and timing (for *_dev pipelines and bench.py) ---------- */
