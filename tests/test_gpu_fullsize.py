@@ -102,16 +102,17 @@ def test_spare_wave_launch_bit_identical(ctx, oracle, variant):
     pipe.matched_filter(free_raw=True)
     got = {}
     try:
-        for sw in (0, -1):
+        for sw in (0, 1, -1):                   # plain launch, one idle wave, two idle waves + CU ticket (auto)
             ctx.set_option("spare_wave", sw)
             pipe.run()
             got[sw] = {k: pipe.fetch(k, 0, B) for k in ("dec", "mu", "freq", "rec")}
             got[sw]["n"] = pipe.n_out().copy()
     finally:
         ctx.set_option("spare_wave", -1)
-    assert np.array_equal(got[0]["n"], got[-1]["n"])
-    for k in ("dec", "mu", "freq", "rec"):
-        assert np.array_equal(got[0][k], got[-1][k]), k
+    for sw in (1, -1):
+        assert np.array_equal(got[0]["n"], got[sw]["n"])
+        for k in ("dec", "mu", "freq", "rec"):
+            assert np.array_equal(got[0][k], got[sw][k]), (sw, k)
     if variant == 0:
         for b in (0, 63, 64, 9999, B - 1):
             t0 = b // 64 * 64
