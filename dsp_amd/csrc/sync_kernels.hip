@@ -564,8 +564,10 @@ __device__ __forceinline__ unsigned wave_slot()
 //   LDS: [ring][queue 2*TQ*64 complex128][flags 2*TQ*64 bytes][more[2]]
 //   Block qb: wave 0 fills queue[qb&1], s_barrier; wave 1 drains it while wave 0
 //   fills the other half.  Every block both waves execute exactly one barrier.
-template <typename IN, int VARIANT, bool SC>
-__global__ __launch_bounds__(256) void sync_split_kernel(SyncParams P)
+// NWV = waves launched per tile: 2, or 3 / 4 with idle waves for the dispatcher (below); separate
+// instantiations so that the plain launch compiles exactly as it did without them (0.9 % at B = 65 536)
+template <typename IN, int VARIANT, bool SC, int NWV>
+__global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
 {
     typedef typename InT<IN>::OS OS;
     typedef typename InT<IN>::OC OC;
@@ -579,7 +581,7 @@ __global__ __launch_bounds__(256) void sync_split_kernel(SyncParams P)
     // in between the live waves land on (0,1) and (2,3).  A wave that has ended counts as arrived
     // at every later s_barrier of its workgroup.
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (blockDim.x == 192 && wv == 1) return;
+    if (NWV == 3 && wv == 1) return;
     int role = wv ? 1 : 0;                                               // 0 = timing, 1 = FLL
     const int tile = blockIdx.x;
     const int b = tile * 64 + lane;
@@ -598,7 +600,7 @@ __global__ __launch_bounds__(256) void sync_split_kernel(SyncParams P)
     typedef __attribute__((address_space(3))) int lds_int;
     lds_int *q_more = (lds_int *)(q_flag + (size_t)2 * TQ * 64);               // [2]
     constexpr int ROFF = (VARIANT == DSP_VARIANT_TED) ? 0 : 1;      // FLL row of queue entry `it` = it + ROFF
-    if (blockDim.x == 256) {
+    if (NWV == 4) {
         // Four waves: the dispatcher puts them on the CU's four SIMDs (order 0, 2, 1, 3 from wherever
         // it stands).  The workgroup draws a ticket from its CU's counter; the two waves on SIMD pair
         // {0,1} (even ticket) or {2,3} (odd) become the timing and the FLL wave, the other two leave.
@@ -853,15 +855,19 @@ static hipError_t launch_in(const SyncParams &P, int variant, bool fll, size_t l
 {
     if (P.TQ > 0) {        // two waves per tile (timing wave + FLL wave)
         int ntiles = (P.B + 63) / 64;
-        void (*k)(SyncParams) =
-            variant == DSP_VARIANT_GARDNER2
-                ? (P.scale ? sync_split_kernel<IN, DSP_VARIANT_GARDNER2, true> : sync_split_kernel<IN, DSP_VARIANT_GARDNER2, false>)
-                : (P.scale ? sync_split_kernel<IN, DSP_VARIANT_TED, true> : sync_split_kernel<IN, DSP_VARIANT_TED, false>);
+        const int nwv = P.spare_wave == 2 && P.cu_tickets ? 4 : P.spare_wave ? 3 : 2;
+        void (*k)(SyncParams);
+#define DSP_SPLIT_PICK(N)                                                                                              \
+    k = variant == DSP_VARIANT_GARDNER2                                                                                \
+            ? (P.scale ? sync_split_kernel<IN, DSP_VARIANT_GARDNER2, true, N> : sync_split_kernel<IN, DSP_VARIANT_GARDNER2, false, N>) \
+            : (P.scale ? sync_split_kernel<IN, DSP_VARIANT_TED, true, N> : sync_split_kernel<IN, DSP_VARIANT_TED, false, N>)
+        if (nwv == 4) { DSP_SPLIT_PICK(4); } else if (nwv == 3) { DSP_SPLIT_PICK(3); } else { DSP_SPLIT_PICK(2); }
+#undef DSP_SPLIT_PICK
         if (lds > 64 * 1024) {     // ring below 64 KiB, queue above it: has to be asked for
             hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(k, dim3(ntiles), dim3(P.spare_wave == 2 && P.cu_tickets ? 256 : P.spare_wave ? 192 : 128), lds, s, P);
+        hipLaunchKernelGGL(k, dim3(ntiles), dim3(64 * nwv), lds, s, P);
         return hipGetLastError();
     }
     switch (variant) {
