@@ -31,16 +31,17 @@ def _best_alignment(dec, centre, span=24):
     return best
 
 
-@pytest.mark.parametrize("seg_len", [32768, 65536])
-def test_capture_2p30(ctx, seg_len):
+# (65536, 2048) is SURVEY.md 8(d)'s config 5 as written; None = the automatic segment length
+@pytest.mark.parametrize("seg_len,warmup", [(32768, 4096), (65536, 4096), (65536, 2048), (None, 2048)])
+def test_capture_2p30(ctx, seg_len, warmup):
     from dsp_amd.pipeline import CapturePipeline
     n, sps, tau0, drift = 1 << 30, 4, 0.3, 2.0e-8
-    pipe = CapturePipeline(ctx, n, sps, seg_len=seg_len, warmup=4096)
+    pipe = CapturePipeline(ctx, n, sps, seg_len=seg_len, warmup=warmup)
     try:
         pipe.generate(SEED, tau0=tau0, drift=drift)
         nsym = pipe.run()
         assert abs(nsym - int(round(n * (1.0 + drift) / sps))) <= 4
-        assert pipe.S == n // seg_len
+        assert pipe.S == n // pipe.seg_len
         info = pipe.info.copy()
         # seg_info rows (first kept row, end row, rotation, rows produced): every window contributed a
         # non-empty share inside what it produced, and the shares add up to the stitched stream
