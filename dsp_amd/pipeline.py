@@ -16,19 +16,11 @@ import numpy as np
 from . import _lib
 from ._lib import CaptureArgs, FirArgs, SyncArgs, check, DSP_C64, DSP_I16
 from .api import rrc_filter
+from .sharding import shard_range  # noqa: F401  (the job partition lives in sharding.py)
 
 _OUT_ELEM = {"rec": 8, "err": 4, "mu": 4, "sig": 8, "freq": 4, "ef": 4, "dec": 1}
 _OUT_DTYPE = {"rec": np.complex64, "err": np.float32, "mu": np.float32, "sig": np.complex64,
               "freq": np.float32, "ef": np.float32, "dec": np.uint8}
-
-
-def shard_range(total: int, rank: int, world: int):
-    """Contiguous block [lo, hi) of `total` independent bursts owned by `rank` of `world`."""
-    if world < 1 or not (0 <= rank < world):
-        raise ValueError("bad rank/world")
-    base, rem = divmod(int(total), int(world))
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
 
 
 class BurstPipeline:
@@ -100,17 +92,22 @@ class BurstPipeline:
         self.ctx.h2d(self.d_raw, X)
 
     def matched_filter(self, free_raw=False):
-        """RX RRC 'same' + / np.std (worker.py:173-178) -> normalised complex64 tiles.
-        Two launches: statistics, then filter * (1/std) with one rounding."""
+        """RX RRC 'same' + np.std (worker.py:173-178) in ONE filter pass: the tiles receive
+        fl32(y64), the pass's own per-chunk statistics give std and 1/std per burst, and the
+        recurrence kernel multiplies by 1/std in float64 as it loads (what dsp_rx_chain does)."""
         f = FirArgs()
         f.src = self.d_raw; f.in_kind = 0; f.start = -1; f.B = self.B; f.N = self.N; f.src_stride = self.N
         f.h = self.d_taps; f.n_taps = self.taps.size; f.rows = self.rows
         f.workspace = self.d_ws; f.workspace_bytes = self.ws_bytes
-        f.tiles = None; f.std_out = self.d_std; f.inv_std_out = self.d_inv
+        f.tiles = self.d_tiles; f.std_out = self.d_std; f.inv_std_out = self.d_inv
         check(self.L.dsp_fir_tiles_dev(self.ctx.handle, C.byref(f)))
-        f.tiles = self.d_tiles; f.std_out = None; f.inv_std_out = None; f.scale = self.d_inv
-        check(self.L.dsp_fir_tiles_dev(self.ctx.handle, C.byref(f)))
+        self._sync_args.scale = self.d_inv
         if free_raw:
+            self.free_raw()
+
+    def free_raw(self):
+        """Release the raw (unfiltered) bursts once the filter has consumed them."""
+        if self.d_raw:
             self.ctx.synchronize()
             self.ctx.free(self.d_raw)
             self.d_raw = None
@@ -150,9 +147,17 @@ class BurstPipeline:
                                 b_lo, b_hi, self.out_rows - 1)
 
     def fetch_input(self, b_lo=0, b_hi=None):
-        """The matched-filtered complex64 bursts the recurrence kernel consumed."""
+        """The matched-filtered complex64 bursts fl32(y64) the recurrence kernel loaded; it multiplies
+        them by fetch_inv_std() in float64 (x' = float64(y32) * (1/std))."""
         b_hi = self.B if b_hi is None else b_hi
         return self.fetch_tiles(self.d_tiles, 8, self.rows, np.complex64, b_lo, b_hi, self.N)
+
+    def fetch_inv_std(self, b_lo=0, b_hi=None):
+        """1/np.std of the filtered bursts [b_lo, b_hi) (float64), the scale of the recurrence loads."""
+        b_hi = self.B if b_hi is None else b_hi
+        inv = np.empty(b_hi - b_lo, np.float64)
+        self.ctx.d2h(inv, self.d_inv + 8 * b_lo)
+        return inv
 
 
 class CapturePipeline:

@@ -8,6 +8,9 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_hash  # noqa: E402  (stdlib-only import: the stamp bench.py checks)
+
 prof, out = sys.argv[1], sys.argv[2]
 want = sys.argv[3] if len(sys.argv) > 3 else "sync_"
 summary = {"source": os.path.basename(prof.rstrip("/")), "kernel_filter": want}
@@ -62,6 +65,8 @@ if "hbm_traffic" in summary and "bench_line" in summary:
                "hbm_bytes_per_launch": summary["hbm_traffic"]["total_bytes_corrected"],
                "fetch_bytes_corrected": summary["hbm_traffic"]["fetch_bytes_corrected"],
                "write_bytes": summary["hbm_traffic"]["write_bytes"],
+               # bench.py reports this figure only while the kernel's sources still hash to this
+               "kernel_source_sha256": kernel_source_hash(),
                "source": os.path.basename(out) + ".json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                          "FETCH_SIZE x2 per MI355X_MICROARCH.md HBM section)"},
               open(os.path.join(os.path.dirname(out) or ".", "traffic.json"), "w"), indent=1)

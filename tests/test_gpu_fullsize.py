@@ -47,12 +47,13 @@ def test_pipeline_fullsize(ctx, oracle, B, split):
         # oracle parity on the first, a middle and the last tile
         for t in (0, (B // 64) // 2, B // 64 - 1):
             X = pipe.fetch_input(t * 64, t * 64 + 64)
+            inv = pipe.fetch_inv_std(t * 64, t * 64 + 64)
             dec = pipe.fetch("dec", t * 64, t * 64 + 64)
             mu = pipe.fetch("mu", t * 64, t * 64 + 64)
             freq = pipe.fetch("freq", t * 64, t * 64 + 64)
             rec = pipe.fetch("rec", t * 64, t * 64 + 64)
             for b in range(0, 64, 3):
-                o = oracle.sync_chain_c64(X[b])
+                o = oracle.sync_chain_c64(X[b], scale=inv[b])
                 n = o["n"]
                 assert n == 2048
                 assert np.array_equal(dec[b, :n], o["dec"])
@@ -117,7 +118,7 @@ def test_spare_wave_launch_bit_identical(ctx, oracle, variant):
         for b in (0, 63, 64, 9999, B - 1):
             t0 = b // 64 * 64
             X = pipe.fetch_input(t0, t0 + 64)
-            o = oracle.sync_chain_c64(X[b - t0])
+            o = oracle.sync_chain_c64(X[b - t0], scale=pipe.fetch_inv_std(b, b + 1)[0])
             assert np.array_equal(got[-1]["dec"][b, :o["n"]], o["dec"])
     pipe.close()
 
