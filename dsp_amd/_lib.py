@@ -107,6 +107,8 @@ def _declare(L):
     L.dsp_destroy.restype = None
     L.dsp_set_stream.argtypes = [vp, vp]
     L.dsp_synchronize.argtypes = [vp]
+    L.dsp_device_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i64)]
+    L.dsp_capture_validate.argtypes = [C.POINTER(CaptureArgs)]
     L.dsp_set_option.argtypes = [vp, C.c_char_p, i64]
     L.dsp_malloc.argtypes = [vp, C.c_size_t, pvp]
     L.dsp_free.argtypes = [vp, vp]
@@ -160,7 +162,8 @@ def _declare(L):
                  "dsp_untile_dev", "dsp_sync_tiles_dev", "dsp_load_iq_i16", "dsp_load_iq_f32",
                  "dsp_fir_same_std", "dsp_rx_chain", "dsp_fir_tiles_dev", "dsp_synth_bursts_dev",
                  "dsp_sync_capture_segmented", "dsp_sync_capture_segmented_dev", "dsp_synth_stream_dev", "dsp_lagrange_resample", "dsp_fll_class", "dsp_diff_corr",
-                 "dsp_cfo_preamble", "dsp_cfo_fourth_power", "dsp_derotate", "dsp_rx_bursts", "dsp_cfo_derotate_dev", "dsp_fll_slicer", "dsp_trim"):
+                 "dsp_cfo_preamble", "dsp_cfo_fourth_power", "dsp_derotate", "dsp_rx_bursts", "dsp_cfo_derotate_dev", "dsp_fll_slicer", "dsp_trim",
+                 "dsp_device_info", "dsp_capture_validate"):
         getattr(L, name).restype = ci
 
 
@@ -210,6 +213,12 @@ class Context:
 
     def synchronize(self):
         check(lib().dsp_synchronize(self.handle))
+
+    def device_info(self):
+        """(compute units, LDS bytes per CU) of the context's device."""
+        n_cu, lds = C.c_int32(), C.c_int64()
+        check(lib().dsp_device_info(self.handle, C.byref(n_cu), C.byref(lds)))
+        return int(n_cu.value), int(lds.value)
 
     def malloc(self, nbytes: int) -> int:
         p = C.c_void_p()

@@ -490,35 +490,37 @@ def diff_corr(signal_iq, preamble_iq, sps, *, ctx=None):
 
 
 def find_preamble_offset(signal_iq, preamble_iq, sps, *, ctx=None):
-    """diff_method.find_preamble_offset (diff_method.py:92-162):
-    returns (offset, signal_aligned, conv_results, conv_max, phase_offset)."""
-    signal_iq = np.asarray(signal_iq)
-    conv_results = diff_corr(signal_iq, preamble_iq, sps, ctx=ctx)
-    conv_max = [(np.argmax(np.abs(c)), np.max(np.abs(c))) for c in conv_results]          # :150
-    values = [val for idx, val in conv_max]                                                # :153
-    offset_index = int(np.argmax(values))
-    offset = conv_max[offset_index][0]
-    phase_offset = offset_index
-    signal_aligned = signal_iq[offset * sps + phase_offset:]                               # :158
-    return offset, signal_aligned, conv_results, conv_max, phase_offset
+    """Same contract as diff_method.find_preamble_offset (diff_method.py:92-162):
+    (offset in symbols, signal from the preamble on, per-phase correlations, per-phase
+    (arg-max, peak height), winning phase).  The correlations come from the device
+    (diff_corr); picking the peak is a handful of host operations."""
+    sig = np.asarray(signal_iq)
+    corr = diff_corr(sig, preamble_iq, sps, ctx=ctx)
+    conv_max = []
+    for c in corr:
+        mag = np.abs(c)
+        k = np.argmax(mag)                       # first maximum, as np.argmax in the reference
+        conv_max.append((k, mag[k]))
+    best_phase = int(np.argmax([height for _, height in conv_max]))     # ties: the lowest phase
+    offset = conv_max[best_phase][0]
+    return offset, sig[offset * sps + best_phase:], corr, conv_max, best_phase
 
 
 def find_optimal_sampling_phase(signal_filtered, preamble_symbols, sps, preamble_length=None):
-    """diff_method.find_optimal_sampling_phase (diff_method.py:41-89): sps correlations of
-    len(preamble) symbols each -- a few hundred multiplies, kept in numpy on the host."""
-    if preamble_length is None:
-        preamble_length = len(preamble_symbols)
-    else:
-        preamble_length = min(preamble_length, len(preamble_symbols))
-    preamble_ref = preamble_symbols[:preamble_length]
-    correlations = np.zeros(sps)
-    for phase in range(sps):
-        sampled = signal_filtered[phase::sps]
-        if len(sampled) < preamble_length:
-            correlations[phase] = 0
-            continue
-        correlations[phase] = np.abs(np.sum(sampled[:preamble_length] * np.conj(preamble_ref)))
-    return np.argmax(correlations), correlations
+    """Same contract as diff_method.find_optimal_sampling_phase (diff_method.py:41-89): for each
+    of the sps decimation phases, |sum(strobes * conj(preamble))| over the first preamble-length
+    strobes (0 where the signal is too short); returns (best phase, the sps magnitudes).
+    sps sums of len(preamble) products: host numpy, nothing worth a launch."""
+    ref = np.asarray(preamble_symbols)
+    n_ref = len(ref) if preamble_length is None else min(preamble_length, len(ref))
+    ref_conj = np.conj(ref[:n_ref])
+    sig = np.asarray(signal_filtered)
+    score = np.zeros(sps)
+    for p in range(sps):
+        strobes = sig[p::sps][:n_ref]
+        if len(strobes) == n_ref:
+            score[p] = np.abs(np.sum(strobes * ref_conj))
+    return np.argmax(score), score
 
 
 # ---------------------------------------------------------------------------

@@ -12,6 +12,8 @@
 
 struct dsp_ctx {
     int device;
+    int n_cu;           // compute units of the device (hipDeviceProp_t::multiProcessorCount)
+    size_t lds_per_cu;  // LDS bytes of one CU = the most one workgroup can be given (160 KiB on gfx950)
     hipStream_t stream;
     bool own_stream;
     hipEvent_t ev0, ev1;
@@ -134,17 +136,37 @@ int dsp_create(int device_id, dsp_ctx **out)
     c->trace = nullptr;
     c->trace_stamps = 0;
 #endif
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    c->stream = nullptr; c->ev0 = nullptr; c->ev1 = nullptr; c->cu_tickets = nullptr;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device_id);
+    if (e == hipSuccess) {
+        c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        c->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor >= 64 * 1024 ? prop.maxSharedMemoryPerMultiProcessor
+                                                                          : (size_t)64 * 1024;
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    }
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
-    c->cu_tickets = nullptr;
     if (e == hipSuccess) e = hipMalloc((void **)&c->cu_tickets, 4096 * sizeof(unsigned));
     if (e == hipSuccess) e = hipMemset(c->cu_tickets, 0, 4096 * sizeof(unsigned));
     if (e != hipSuccess) {
+        // release whatever was created before the step that failed
+        if (c->cu_tickets) (void)hipFree(c->cu_tickets);
+        if (c->ev1) (void)hipEventDestroy(c->ev1);
+        if (c->ev0) (void)hipEventDestroy(c->ev0);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
         delete c;
         return fail(DSP_E_HIP, "context creation failed: %s", hipGetErrorString(e));
     }
     *out = c;
+    return DSP_OK;
+}
+
+int dsp_device_info(dsp_ctx *c, int32_t *n_cu, int64_t *lds_per_cu)
+{
+    if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    if (n_cu) *n_cu = c->n_cu;
+    if (lds_per_cu) *lds_per_cu = (int64_t)c->lds_per_cu;
     return DSP_OK;
 }
 
@@ -173,6 +195,7 @@ int dsp_trim(dsp_ctx *c)
 int dsp_set_stream(dsp_ctx *c, void *s)
 {
     if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     c->stream = (hipStream_t)s;
@@ -183,6 +206,7 @@ int dsp_set_stream(dsp_ctx *c, void *s)
 int dsp_synchronize(dsp_ctx *c)
 {
     if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DSP_OK;
 }
@@ -233,18 +257,21 @@ int dsp_malloc(dsp_ctx *c, size_t bytes, void **dptr)
 int dsp_free(dsp_ctx *c, void *dptr)
 {
     if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
     if (dptr) HIP_TRY(hipFree(dptr));
     return DSP_OK;
 }
 int dsp_memset(dsp_ctx *c, void *dptr, int value, size_t bytes)
 {
     if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemsetAsync(dptr, value, bytes, c->stream));
     return DSP_OK;
 }
 int dsp_h2d(dsp_ctx *c, void *dptr, const void *hptr, size_t bytes)
 {
     if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DSP_OK;
@@ -252,6 +279,7 @@ int dsp_h2d(dsp_ctx *c, void *dptr, const void *hptr, size_t bytes)
 int dsp_d2h(dsp_ctx *c, void *hptr, const void *dptr, size_t bytes)
 {
     if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DSP_OK;
@@ -267,12 +295,14 @@ int dsp_stream_copy_dev(dsp_ctx *c, void *d_dst, const void *d_src, size_t bytes
 int dsp_timer_start(dsp_ctx *c)
 {
     if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     return DSP_OK;
 }
 int dsp_timer_stop(dsp_ctx *c, float *ms)
 {
     if (!c || !ms) return fail(DSP_E_ARG, "ctx/ms is NULL");
+    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipEventSynchronize(c->ev1));
     HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
@@ -408,13 +438,22 @@ int dsp_sync_tiles_dev(dsp_ctx *c, const dsp_sync_args *a)
     const bool can_split = fll && a->variant != 2 && P.half_len == 0;
     const int n_store_t = count_nonnull({P.rec, P.terr, P.mu, P.pos});
     const int n_store_f = count_nonnull({P.sig, P.freq, P.ef, P.dec});
-    int per_cu = (ntiles + 255) / 256;
+    int per_cu = (ntiles + c->n_cu - 1) / c->n_cu;
     if (per_cu < 1) per_cu = 1;
-    const size_t budget_all = ((size_t)160 * 1024 / per_cu) & ~(size_t)2047;   // LDS is allocated in coarse blocks
+    const size_t queue_min = (size_t)2 * 64 * 17 + 16;               // hand-off queue with TQ = 1
+    // Residency heuristic: the LDS share that lets every tile of the launch be resident at once.  It
+    // only steers the ring / queue sizes: with more tiles than that allows (B > ~160 k bursts) the
+    // share stops at the smallest two-wave shape (32-row ring + one-symbol queue) and the surplus
+    // tiles simply queue on the CUs.  The hard limit is the workgroup's LDS maximum, checked below.
+    size_t budget_all = (c->lds_per_cu / per_cu) & ~(size_t)2047;   // LDS is allocated in coarse blocks
+    {
+        const size_t least = ((size_t)32 * 64 * elem + queue_min + 32 + 2047) & ~(size_t)2047;
+        if (budget_all < least) budget_all = least;
+        if (budget_all > c->lds_per_cu) budget_all = c->lds_per_cu;
+    }
     // the input ring must stay below 64 KiB (the LDS-DMA base register M0 addresses no more); the
     // two-wave kernel's hand-off queue may lie above it when the workgroup may have more LDS
     const size_t budget = budget_all > 64 * 1024 ? 64 * 1024 : budget_all;
-    const size_t queue_min = (size_t)2 * 64 * 17 + 16;               // hand-off queue with TQ = 1
     size_t lds = 0;
     bool split = can_split && c->split != 0;
     for (;;) {
@@ -457,7 +496,8 @@ int dsp_sync_tiles_dev(dsp_ctx *c, const dsp_sync_args *a)
     }
     if (c->lds_pad >= 0) lds += (size_t)c->lds_pad;
     else if (budget > lds) lds = budget;
-    if (lds > budget_all) return fail(DSP_E_ARG, "sync: %zu bytes of LDS needed, %zu available per workgroup", lds, budget_all);
+    if (lds > c->lds_per_cu)
+        return fail(DSP_E_ARG, "sync: %zu bytes of LDS needed, a workgroup can have %zu", lds, c->lds_per_cu);
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(launch_sync(P, a->dtype == DSP_C128, a->variant, fll, lds, c->stream));
     return DSP_OK;
@@ -468,6 +508,7 @@ int dsp_tile_bursts_dev(dsp_ctx *c, const void *d_src, int dtype, int64_t B, int
 {
     if (!c || !d_src || !d_tiles) return fail(DSP_E_ARG, "tile: NULL argument");
     if (rows < N || B < 0) return fail(DSP_E_ARG, "tile: rows < N");
+    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(launch_tile_from_bursts(d_src, src_stride, d_lens, (int)N, (int)B, d_tiles, (int)rows,
                                     dtype == DSP_C128 ? 16 : 8, c->stream));
     return DSP_OK;
@@ -478,6 +519,7 @@ int dsp_untile_dev(dsp_ctx *c, const void *d_tiles, int elem_bytes, int64_t rows
 {
     if (!c || !d_tiles || !d_dst) return fail(DSP_E_ARG, "untile: NULL argument");
     if (ncopy > rows) ncopy = rows;
+    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(launch_bursts_from_tiles(d_tiles, (int)rows, (int)B, d_dst, dst_stride, (int)ncopy,
                                      elem_bytes, c->stream));
     return DSP_OK;
@@ -1229,9 +1271,9 @@ int64_t dsp_capture_segments(int64_t n_samples, int64_t seg_len)
     return (n_samples + seg_len - 1) / seg_len;
 }
 
-int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
+int dsp_capture_validate(const dsp_capture_args *a)
 {
-    if (!c || !a) return fail(DSP_E_ARG, "ctx/args is NULL");
+    if (!a) return fail(DSP_E_ARG, "capture: args is NULL");
     if (!a->x || !a->dec) return fail(DSP_E_ARG, "capture: x / dec is NULL");
     if (a->in_kind != DSP_I16 && a->in_kind != DSP_C64) return fail(DSP_E_ARG, "capture: in_kind must be DSP_I16 or DSP_C64");
     if (a->sps < 1 || a->sps > 64) return fail(DSP_E_ARG, "capture: sps out of range");
@@ -1240,13 +1282,27 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
     if (a->warmup < 0) return fail(DSP_E_ARG, "capture: negative warm-up");
     if (a->h && (a->n_taps < 1 || a->n_taps > 4096)) return fail(DSP_E_ARG, "capture: bad n_taps");
     if (!(a->y > 0.0)) return fail(DSP_E_ARG, "capture: y must be > 0");
+    if (dsp_capture_segments(a->n_samples, a->seg_len) > (1 << 24)) return fail(DSP_E_ARG, "capture: too many segments");
+    // A window's symbol positions are kept as float32 (exact integers up to 2^24, spacing <= 0.5
+    // sample below 2^23): the stitch decides on half a symbol, so a window may span at most 2^23
+    // samples.  (The windows of a capture are ~3e4 samples; this bounds seg_len + warm-up.)
+    const int64_t Nw = a->seg_len + a->warmup * (int64_t)a->sps + 4 * (int64_t)a->sps + 8;
+    if (a->warmup >= (1LL << 30) || Nw > (1LL << 23))
+        return fail(DSP_E_ARG, "capture: window of %lld samples (seg_len + warm-up) exceeds 2^23", (long long)Nw);
+    return DSP_OK;
+}
+
+int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
+{
+    if (!c || !a) return fail(DSP_E_ARG, "ctx/args is NULL");
+    {
+        const int rc = dsp_capture_validate(a);
+        if (rc != DSP_OK) return rc;
+    }
     const int64_t n = a->n_samples, seg = a->seg_len;
-    const int64_t S64 = dsp_capture_segments(n, seg);
-    if (S64 > (1 << 24)) return fail(DSP_E_ARG, "capture: too many segments");
-    const int S = (int)S64, sps = a->sps;
+    const int S = (int)dsp_capture_segments(n, seg), sps = a->sps;
     const int64_t lead = a->warmup * sps, tail = 4 * (int64_t)sps + 8;
     const int64_t Nw = seg + lead + tail;                  // longest window
-    if (Nw >= (1LL << 30)) return fail(DSP_E_ARG, "capture: window too long");
     const int64_t rows = dsp_tile_rows(Nw), out_rows = Nw / sps + 8, ntiles = (S + 63) / 64;
     hipStream_t st = c->stream;
     HIP_TRY(hipSetDevice(c->device));
@@ -1269,21 +1325,24 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
     d_j1.p = d_j0.as<int>() + S; d_rot.p = d_j0.as<int>() + 2 * (size_t)S; d_nout.p = d_j0.as<int>() + 3 * (size_t)S;
     d_status.p = small.take((size_t)S * 4);
     d_pl.p = small.take((size_t)S * 8); d_off.p = small.take((size_t)(S + 1) * 8);
+    // ---- windows -> tiles (optionally through the matched filter) ------------------------
+    ScratchRef d_peak, d_c64, d_ws, d_inv, d_lo, d_hi, d_part, d_mu0;
+    d_peak.p = small.take(16);
+    d_lo.p = small.take((size_t)S * 4); d_hi.p = small.take((size_t)S * 4);
+    d_inv.p = small.take((size_t)S * 8);
+    d_part.p = small.take((size_t)1024 * 32);
+    d_mu0.p = small.take((size_t)S * 8);
+    if (small.off > small.cap) return fail(DSP_E_NOMEM, "capture: scratch block too small");
     // the filter pass writes every row of every lane (zeros past a window's end and in the idle lanes
     // of the last tile: its chunks cover ceil(Nw / CH) * CH >= rows); only the copy path needs clearing
     if (!a->h) HIP_TRY(hipMemsetAsync(d_tiles.p, 0, (size_t)ntiles * rows * 64 * 8, st));
-
-    // ---- windows -> tiles (optionally through the matched filter) ------------------------
-    ScratchRef d_peak, d_c64, d_ws, d_inv, d_lo, d_hi, d_part;
     const float *in_scale = nullptr;
     if (a->in_kind == DSP_I16) {
-        d_peak.p = small.take(16);
         if (!a->h) HIP_TRY(ctx_scratch(c, 7, (size_t)n * 8, &d_c64.p));
         HIP_TRY(launch_iq_i16(a->x, n, a->normalize, d_peak.as<unsigned>(), d_peak.as<float>() + 1,
                               a->h ? nullptr : d_c64.p, st));
         in_scale = d_peak.as<float>() + 1;
     }
-    d_lo.p = small.take((size_t)S * 4); d_hi.p = small.take((size_t)S * 4);
     HIP_TRY(launch_seg_windows(S, n, seg, lead, tail, d_starts.as<int64_t>(), d_lens.as<int>(), d_lo.as<int>(),
                                d_hi.as<int>(), st));
     const double *d_scale = nullptr;
@@ -1296,8 +1355,6 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
         if (!fir_plan(a->in_kind, a->n_taps, (int)Nw, Q))
             return fail(DSP_E_ARG, "capture: %d taps are too many for the LDS-tiled filter", a->n_taps);
         HIP_TRY(ctx_scratch(c, 6, (size_t)S * Q.nchunk * 32, &d_ws.p));
-        d_inv.p = small.take((size_t)S * 8);
-        d_part.p = small.take((size_t)1024 * 32);
         Q.src = a->x; Q.starts = d_starts.as<int64_t>(); Q.n_total = n; Q.lens = d_lens.as<int>();
         Q.stat_lo = d_lo.as<int>(); Q.stat_hi = d_hi.as<int>();
         Q.len_all = (int)Nw; Q.B = S; Q.h = a->h; Q.M = a->n_taps; Q.start = (a->n_taps - 1) / 2;
@@ -1319,11 +1376,8 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
                                         d_starts.as<int64_t>()));
     }
 
-    if (small.off > small.cap) return fail(DSP_E_NOMEM, "capture: scratch block too small");
     // ---- initial timing phase per window (strobe energy), unless the caller fixes mu0 ------------
-    ScratchRef d_mu0;
     if (a->acquire) {
-        d_mu0.p = small.take((size_t)S * 8);
         HIP_TRY(launch_seg_phase(d_tiles.p, (int)rows, d_lens.as<int>(), S, sps, DSP_ACQUIRE_SYMBOLS,
                                  d_mu0.as<double>(), st));
     }
@@ -1331,7 +1385,7 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
     // ---- the batched recurrence over the windows -------------------------------------------
     dsp_sync_args sa;
     memset(&sa, 0, sizeof(sa));
-    sa.mu0_per = d_mu0.as<double>();
+    sa.mu0_per = a->acquire ? d_mu0.as<double>() : nullptr;
     sa.x = d_tiles.p; sa.dtype = DSP_C64; sa.variant = DSP_GARDNER2; sa.B = S; sa.N = Nw; sa.in_rows = rows;
     sa.lens = d_lens.as<int32_t>(); sa.scale = d_scale; sa.sps = sps; sa.alpha = a->alpha; sa.mu0 = a->mu0; sa.do_fll = 1;
     sa.Bn = a->Bn; sa.y = a->y; sa.mu = a->mu ? d_mu.p : nullptr; sa.pos = d_pos.p; sa.dec = d_dec.as<uint8_t>(); sa.freq = a->freq ? d_freq.p : nullptr;

@@ -680,8 +680,12 @@ __global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
             DSP_TR(trp, 0);
             if (ring) tl.advance(blk, sps, T, P.C, P.nwait);
             DSP_TR(trp, 9);
+            // the steady path's stores address a row by a 32-bit byte offset from the tile's base: a
+            // block whose last row would pass 4 GiB (row 2^22 of a complex128 output) takes the
+            // size_t path below instead
             bool steady = steady_ok && all_active && tl.win_lo > 0 && tl.win_hi + 2 * sps + 1 <= min_len &&
-                          it + T + ROFF < cap_rows;
+                          it + T + ROFF < cap_rows &&
+                          (unsigned long long)(it + T + ROFF + 1) * 64ull * sizeof(OC) <= 0xffffffffull;
             for (int t = 0; t < T; t++, it++) {
                 DSP_TR(trp, 0);
                 bool done = false;

@@ -14,25 +14,35 @@ import numpy as np
 from .api import filter_samples
 
 
-class Generation:
-    def __init__(self, constellation, preamble_length, signal_length, sps, Frel, Noise_power, N, Delay):
-        self.constellation = constellation
-        self.preamble_length = preamble_length
-        self.signal_length = signal_length
-        self.sps = sps
-        self.Frel = Frel
-        self.Noise_power = Noise_power
-        self.N = N
-        self.Delay = Delay
+_PARAMS = ("constellation", "preamble_length", "signal_length", "sps", "Frel", "Noise_power", "N", "Delay")
 
-    def generate(self):                                     # worker.py:350-358
+
+class Generation:
+    def __init__(self, *args, **kwargs):
+        """Generation(constellation, preamble_length, signal_length, sps, Frel, Noise_power, N, Delay):
+        the parameter names and order of worker.Generation (worker.py:340), kept as attributes."""
+        if len(args) > len(_PARAMS):
+            raise TypeError(f"Generation takes {len(_PARAMS)} parameters: {', '.join(_PARAMS)}")
+        given = dict(zip(_PARAMS, args))
+        for name, value in kwargs.items():
+            if name not in _PARAMS or name in given:
+                raise TypeError(f"unexpected or repeated parameter {name!r}")
+            given[name] = value
+        missing = [n for n in _PARAMS if n not in given]
+        if missing:
+            raise TypeError(f"missing parameters: {', '.join(missing)}")
+        for name in _PARAMS:
+            setattr(self, name, given[name])
+
+    def generate(self):
+        """(preamble symbols, noisy baseband samples, symbols of one burst) -- the stages in the
+        reference's order (worker.py:350-358); the draws happen in generate_preamble,
+        generate_signal and add_noise, in that order."""
         preamble = self.generate_preamble()
-        samples, symbols = self.generate_signal(preamble)
-        samples = self.upsample(samples)
-        samples = self.filter_samples(samples)
-        samples = self.frequency_offset(samples)
-        samples = self.add_noise(samples)
-        return preamble, samples, symbols
+        stream, symbols = self.generate_signal(preamble)
+        for stage in (self.upsample, self.filter_samples, self.frequency_offset, self.add_noise):
+            stream = stage(stream)
+        return preamble, stream, symbols
 
     def _alphabet(self, payload):
         """The symbol alphabets of worker.py:361-376 (preamble) and :382-397 (payload); they differ
@@ -76,12 +86,18 @@ class Generation:
         return filter_samples(samples, self.sps, 10, 0.35)
 
     def frequency_offset(self, samples):                    # :421-423
-        return samples * np.exp(1j * 2 * np.pi * self.Frel * np.arange(len(samples)))
+        # the product is formed left to right exactly as the reference writes it: a seeded run is
+        # compared bit for bit and any other association rounds differently
+        rotation = np.exp(1j * 2 * np.pi * self.Frel * np.arange(len(samples)))
+        return samples * rotation
 
     def add_noise(self, samples):                           # :425-427
-        noise = (np.random.normal(0, self.Noise_power, len(samples))
-                 + 1j * np.random.normal(0, self.Noise_power, len(samples))) / np.sqrt(2)
-        return samples + noise
+        # two draws of len(samples) normals each, in-phase first: the reference's order of
+        # consumption from numpy's global generator, which a seeded comparison depends on
+        n, sigma = len(samples), self.Noise_power
+        in_phase = np.random.normal(0, sigma, n)
+        quadrature = np.random.normal(0, sigma, n)
+        return samples + (in_phase + 1j * quadrature) / np.sqrt(2)
 
 
 def save_as_pcm_float32_iq(x, filename):

@@ -49,6 +49,9 @@ void dsp_destroy(dsp_ctx *ctx);
 const char *dsp_last_error(void);
 int dsp_set_stream(dsp_ctx *ctx, void *hip_stream);      /* adopt an external hipStream_t */
 int dsp_synchronize(dsp_ctx *ctx);
+/* what the context read from hipGetDeviceProperties when it was created: compute units and the LDS
+ * bytes of one CU (= the most one workgroup can be given); either pointer may be NULL.  Utility. */
+int dsp_device_info(dsp_ctx *ctx, int32_t *n_cu, int64_t *lds_per_cu);
 int dsp_set_option(dsp_ctx *ctx, const char *name, int64_t value); /* tuning knobs: "ring_rows" (LDS ring rows, 0 auto),
    "lds_pad", "split" (-1 auto / 0 one wave per tile / 1 two), "queue_block" (hand-off block, 0 auto),
    "prio_period" (rotate wave priorities every N DMA blocks, 0 off), "spare_wave" (two-wave kernel
@@ -330,6 +333,12 @@ typedef struct dsp_capture_args {
 /* The segment-parallel calls keep their large device work buffers (window tiles, per-window output
  * tiles) in the context between calls; dsp_trim releases them (dsp_destroy does too).           */
 int dsp_trim(dsp_ctx *ctx);
+/* The argument checks of the two calls below as a function of its own (no device needed): DSP_OK, or
+ * DSP_E_ARG with the reason in dsp_last_error().  Limits: sps 1..64; seg_len a multiple of sps and
+ * >= 16 symbols; at most 2^24 segments; a window (seg_len + warmup*sps + 4*sps + 8 samples) of at
+ * most 2^23 samples -- symbol positions inside a window are float32 and the stitch decides on half a
+ * symbol.  x / dec are only checked for NULL.                                                     */
+int dsp_capture_validate(const dsp_capture_args *args);
 int dsp_sync_capture_segmented(dsp_ctx *ctx, const dsp_capture_args *args);
 int dsp_sync_capture_segmented_dev(dsp_ctx *ctx, const dsp_capture_args *args);
 int64_t dsp_capture_segments(int64_t n_samples, int64_t seg_len);   /* S = ceil(n / seg_len) */

@@ -67,3 +67,33 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
                 assert "liboracle" not in txt and "dsp_oracle" not in txt, f
+
+
+def test_capture_argument_bounds_without_gpu():
+    """dsp_capture_validate: the argument checks of the segment-parallel entry points, callable
+    without a device.  A window longer than 2^23 samples is refused (float32 symbol positions
+    cannot separate half-symbol steps beyond that), as are the other malformed shapes."""
+    import dsp_amd
+    from dsp_amd._lib import CaptureArgs
+    L = dsp_amd.lib()
+    x = np.zeros(64, np.int16)
+    dec = np.zeros(64, np.uint8)
+
+    def args(**kw):
+        a = CaptureArgs()
+        a.x = x.ctypes.data; a.dec = dec.ctypes.data; a.in_kind = dsp_amd.DSP_I16
+        a.n_samples = 1 << 30; a.sps = 4; a.seg_len = 32768; a.warmup = 4096; a.y = 1.0
+        a.capacity = 1 << 30
+        for k, v in kw.items():
+            setattr(a, k, v)
+        return a
+
+    assert L.dsp_capture_validate(C.byref(args())) == 0
+    assert L.dsp_capture_validate(C.byref(args(seg_len=1 << 22, warmup=1 << 19))) == 0      # 6.3 M samples
+    for bad in (dict(seg_len=1 << 23), dict(seg_len=1 << 22, warmup=(1 << 20) + 1), dict(warmup=1 << 40)):
+        assert L.dsp_capture_validate(C.byref(args(**bad))) == -1, bad
+        assert b"2^23" in L.dsp_last_error()
+    for bad in (dict(sps=0), dict(sps=65), dict(seg_len=30), dict(seg_len=32770), dict(warmup=-1), dict(y=0.0),
+                dict(n_samples=4), dict(in_kind=dsp_amd.DSP_C128), dict(x=None), dict(seg_len=16 * 4, n_samples=1 << 31)):
+        assert L.dsp_capture_validate(C.byref(args(**bad))) == -1, bad
+    assert L.dsp_capture_validate(None) == -1

@@ -141,3 +141,53 @@ def test_spare_wave_complex128_host_path(ctx):
         ctx.set_option("spare_wave", -1)
     for k in ("sig", "dec", "mu", "freq", "n_out"):
         assert np.array_equal(out[0][k], out[-1][k]), k
+
+
+def test_more_tiles_than_lds_residency_allows(ctx):
+    """B = 200 000 bursts = 3125 tiles, 13 per CU: more than the per-CU LDS can hold at once.  The
+    residency budget only steers the ring / queue sizes (the surplus tiles queue on the CUs); the
+    launch must not be refused, and every tile must produce the bits of a 64-burst call."""
+    import dsp_amd
+    n_cu, lds = ctx.device_info()
+    assert n_cu == 256 and lds == 160 * 1024                      # MI355X; the host code reads both
+    rng = np.random.default_rng(17)
+    n_sym = 24
+    q = rng.integers(0, 4, (64, n_sym))
+    sym = ((1 - 2 * (q & 1)) + 1j * (1 - 2 * (q >> 1))) / np.sqrt(2)
+    x64 = (np.repeat(sym, 4, axis=1) + 0.05 * (rng.standard_normal((64, 4 * n_sym))
+                                               + 1j * rng.standard_normal((64, 4 * n_sym)))).astype(np.complex64)
+    ref = dsp_amd.sync_chain_batch(x64, 4, 0.007, 0.0, 0.03, 1, ctx=ctx)
+    B = 200000
+    X = np.tile(x64, (B // 64, 1))
+    got = dsp_amd.sync_chain_batch(X, 4, 0.007, 0.0, 0.03, 1, ctx=ctx)
+    assert (got["n_out"] == np.tile(ref["n_out"], B // 64)).all()
+    for k in ("rec", "err", "mu", "sig", "freq", "ef", "dec"):
+        g = got[k].reshape(B // 64, 64, -1)
+        assert (g == ref[k][None]).all(), k
+    # the complex128 form reaches the limit at half as many tiles per CU
+    B2 = 96000
+    X2 = np.tile(x64.astype(np.complex128), (B2 // 64, 1))
+    ref2 = dsp_amd.sync_chain_batch(x64.astype(np.complex128), 4, 0.007, 0.0, 0.03, 1, outputs=("rec", "dec", "freq"), ctx=ctx)
+    got2 = dsp_amd.sync_chain_batch(X2, 4, 0.007, 0.0, 0.03, 1, outputs=("rec", "dec", "freq"), ctx=ctx)
+    for k in ("rec", "dec", "freq"):
+        assert (got2[k].reshape(B2 // 64, 64, -1) == ref2[k][None]).all(), k
+
+
+def test_one_burst_beyond_4gib_of_output_rows(ctx, oracle):
+    """A single complex128 burst of 2^22 + 3000 symbols: the `recovered` tile passes 4 GiB at row 2^22
+    (64 lanes x 16 bytes per row), where the steady path's 32-bit store offsets would wrap.  Bit-exact
+    against the oracle over the whole length (Bn = 1e-6: the FLL horizon is ~1e8 symbols)."""
+    import dsp_amd
+    rng = np.random.default_rng(23)
+    n_sym = (1 << 22) + 3000
+    q = rng.integers(0, 4, n_sym)
+    sym = ((1 - 2 * (q & 1)) + 1j * (1 - 2 * (q >> 1))) / np.sqrt(2)
+    x = np.repeat(sym, 4)
+    x += 0.05 * (rng.standard_normal(x.size) + 1j * rng.standard_normal(x.size))
+    r = dsp_amd.sync_chain_batch(x[None, :], 4, 0.007, 0.0, 1e-6, 1, outputs=("rec", "dec"), ctx=ctx)
+    rec, err, mu = oracle.gardner_timing_recovery(x, 4, 0.007, 0.0)
+    n = len(rec)
+    assert r["n_out"][0] == n and n > (1 << 22)
+    assert np.array_equal(r["rec"][0, :n], rec)
+    out = oracle.fll_func(rec, 1e-6, 1)
+    assert np.array_equal(r["dec"][0, :n], oracle.quadrants(out[0]))

@@ -21,6 +21,31 @@ def _chain_oracle(O, y32, sps=4, alpha=0.007, Bn=0.03, scale=1.0):
     return O.sync_chain_c64(y32, sps=sps, alpha=alpha, Bn=Bn, y=1.0, scale=scale)
 
 
+def _fll_self_consistency(x, out, freq, ef, Bn, y=1.0):
+    """What survives the chaos beyond the stability horizon: the device's outputs obey the
+    recurrence of fll_func.py:14-26 step by step over the FULL length, whatever trajectory the
+    loop is on.  Each step is recomputed in numpy from the device's own previous state:
+      curr_freq_list[i] = curr_freq_list[i-1] + ef_n_list[i]                 (:25-26, exact)
+      signal_list[i]    = x[i] * exp(-1j * 2*pi * curr_freq_list[i-1] * i)   (:16-18)
+      ef_n_list[i]      = error_i * kp + integrator_i,  integrator_i = integrator_(i-1) + error_i * ki,
+                          error_i = angle(signal_list[i] * conj(decided_i))  (:19-24)
+      |error_i| <= pi/4 for a QPSK slicer (no exactly-zero components here), which bounds |ef_n|."""
+    import dsp_amd
+    kp, ki = dsp_amd.fll_gains(Bn, y)
+    n = len(x)
+    i = np.arange(n, dtype=np.float64)
+    f_prev = np.concatenate([[0.0], freq[:-1]])
+    assert np.array_equal(freq, f_prev + ef)
+    want = x * np.exp(-1j * (2 * np.pi * f_prev * i))
+    assert np.max(np.abs(out - want)) < 1e-11 * max(1.0, np.max(np.abs(x)))
+    decided = (np.sign(out.real) + 1j * np.sign(out.imag)) / np.sqrt(2)
+    err = np.angle(out * np.conj(decided))
+    assert np.max(np.abs(err)) <= np.pi / 4 + 1e-12
+    integ = np.cumsum(err * ki)
+    assert np.max(np.abs(ef - (err * kp + integ))) < 1e-15 + 1e-12 * np.max(np.abs(ef))
+    assert np.all(np.abs(ef) <= np.pi / 4 * (kp + ki * (i + 1)) + 1e-15)
+
+
 def test_dropin_gardner_config1_bit_exact(ctx):
     import dsp_amd
     g = golden("g_config1")
@@ -48,6 +73,8 @@ def test_dropin_fll_config1_stable_horizon(ctx):
     assert np.max(np.abs(out[:H] - g["fll_out"][:H])) < SIG_TOL
     dec = (out.real < 0) + 2 * (out.imag < 0)
     assert np.array_equal(dec[:H], g["dec"][:H])
+    # the 7199 symbols beyond the horizon: the recurrence itself, step by step, on all 10 499
+    _fll_self_consistency(g["rec"], out, freq, ef, 0.03)
 
 
 def test_dropin_fll_config2_full(ctx):
@@ -66,6 +93,7 @@ def test_dropin_fll_config2_full(ctx):
     dec = (out.real < 0) + 2 * (out.imag < 0)
     assert np.array_equal(dec[:H], g["dec"][:H])
     assert list(dec[:16]) == [0, 3, 3, 1, 1, 3, 0, 1, 2, 3, 0, 2, 2, 1, 1, 3]
+    _fll_self_consistency(rec, out, freq, ef, 0.03)          # all 10 470 symbols, see config 1
 
 
 def test_dropin_gardner_ted_hw1(ctx):
