@@ -24,6 +24,8 @@ struct dsp_ctx {
     int lead_copy;      // segment-parallel mode, warm-up rows: 0 = the filter's second store, 1 = seg_lead_copy_k, 2 = filtered per window
     int spare_wave;     // split kernel, idle waves for SIMD balance: -1 auto, 0 never, 1 three waves, 2 four waves + CU tickets
     unsigned *cu_tickets;   // [4096] per-CU workgroup counters for the four-wave launch
+    int fir_stream;     // matched filter of <= 41 taps: 1 = fir_stream_kernel (default), 0 = the tap-blocked kernel
+    double *fir_taps;   // [64] the stream kernel's zero-padded taps
     int prio_period;    // split kernel: priority rotation period in DMA blocks (power of two), 0 = off
     // grow-only device scratch kept between calls of the segment-parallel mode (its window tiles are
     // gigabytes: hipMalloc / hipFree per call cost milliseconds); released by dsp_trim / dsp_destroy
@@ -132,6 +134,8 @@ int dsp_create(int device_id, dsp_ctx **out)
     c->prio_period = 0;
     c->spare_wave = -1;
     c->lead_copy = 0;
+    c->fir_stream = 1;
+    c->fir_taps = nullptr;
 #ifdef DSP_TRACE
     c->trace = nullptr;
     c->trace_stamps = 0;
@@ -149,8 +153,10 @@ int dsp_create(int device_id, dsp_ctx **out)
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipMalloc((void **)&c->cu_tickets, 4096 * sizeof(unsigned));
     if (e == hipSuccess) e = hipMemset(c->cu_tickets, 0, 4096 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->fir_taps, 64 * sizeof(double));
     if (e != hipSuccess) {
         // release whatever was created before the step that failed
+        if (c->fir_taps) (void)hipFree(c->fir_taps);
         if (c->cu_tickets) (void)hipFree(c->cu_tickets);
         if (c->ev1) (void)hipEventDestroy(c->ev1);
         if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -177,6 +183,7 @@ void dsp_destroy(dsp_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     ctx_trim(c);
     if (c->cu_tickets) (void)hipFree(c->cu_tickets);
+    if (c->fir_taps) (void)hipFree(c->fir_taps);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -228,6 +235,9 @@ int dsp_set_option(dsp_ctx *c, const char *name, int64_t value)
     } else if (!strcmp(name, "trace_stamps")) {
         c->trace_stamps = (int)value;
 #endif
+    } else if (!strcmp(name, "fir_stream")) {
+        if (value < 0 || value > 1) return fail(DSP_E_ARG, "fir_stream must be 0 or 1");
+        c->fir_stream = (int)value;
     } else if (!strcmp(name, "lead_copy")) {
         if (value < 0 || value > 2) return fail(DSP_E_ARG, "lead_copy must be 0, 1 or 2");
         c->lead_copy = (int)value;
@@ -647,9 +657,10 @@ static int in_elem_bytes(int in_kind) { return in_kind == DSP_C128 ? 16 : (in_ki
 
 int64_t dsp_fir_workspace_bytes(int in_kind, int64_t B, int64_t N, int n_taps)
 {
-    FirParams P;
-    if (n_taps < 1 || !fir_plan(in_kind, n_taps, (int)N, P)) return 0;
-    return (int64_t)B * P.nchunk * 4 * 8;
+    FirParams P, Q;
+    if (n_taps < 1 || !fir_plan(in_kind, n_taps, (int)N, P, false)) return 0;
+    fir_plan(in_kind, n_taps, (int)N, Q, true);          // either kernel's chunking fits
+    return (int64_t)B * (P.nchunk > Q.nchunk ? P.nchunk : Q.nchunk) * 4 * 8;
 }
 
 int dsp_fir_tiles_dev(dsp_ctx *c, const dsp_fir_args *a)
@@ -662,8 +673,9 @@ int dsp_fir_tiles_dev(dsp_ctx *c, const dsp_fir_args *a)
     if (a->tiles && a->rows < a->N) return fail(DSP_E_ARG, "fir: rows < N");
     FirParams P;
     memset(&P, 0, sizeof(P));
-    if (!fir_plan(a->in_kind, a->n_taps, (int)a->N, P))
+    if (!fir_plan(a->in_kind, a->n_taps, (int)a->N, P, c->fir_stream != 0))
         return fail(DSP_E_ARG, "fir: %d taps are too many for the LDS-tiled kernel", a->n_taps);
+    P.h_pad = c->fir_taps;
     const bool want_std = a->std_out || a->inv_std_out;
     if (want_std && (!a->workspace || a->workspace_bytes < (int64_t)a->B * P.nchunk * 32))
         return fail(DSP_E_ARG, "fir: workspace too small (need %lld bytes)", (long long)a->B * P.nchunk * 32);
@@ -1352,8 +1364,9 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
         // into the np.std of the whole filtered stream; 1/std is applied by the recurrence kernel
         FirParams Q;
         memset(&Q, 0, sizeof(Q));
-        if (!fir_plan(a->in_kind, a->n_taps, (int)Nw, Q))
+        if (!fir_plan(a->in_kind, a->n_taps, (int)Nw, Q, c->fir_stream != 0))
             return fail(DSP_E_ARG, "capture: %d taps are too many for the LDS-tiled filter", a->n_taps);
+        Q.h_pad = c->fir_taps;
         HIP_TRY(ctx_scratch(c, 6, (size_t)S * Q.nchunk * 32, &d_ws.p));
         Q.src = a->x; Q.starts = d_starts.as<int64_t>(); Q.n_total = n; Q.lens = d_lens.as<int>();
         Q.stat_lo = d_lo.as<int>(); Q.stat_hi = d_hi.as<int>();

@@ -91,11 +91,13 @@ struct FirParams {
     int nchunk, CH, W, stride;
     int skip_rows;            // tiles > 0 skip the chunks that end at or before this output row (0 = none)
     int waves;                // waves per workgroup: 0 = auto (8 where the chunk divides), 4 = always 4
+    int stream;               // set by fir_plan: 1 = fir_stream_kernel (<= 41 taps, float32 staging)
+    double *h_pad;            // device scratch for the stream kernel's zero-padded taps (>= 48 doubles)
     int feed_lead;            // 1: every window also stores its rows [shift, shift + skip_rows) as rows [0, skip_rows)
                               //    of its successor (shift = starts[b+1] - starts[b]; successors in tiles > 0 only)
 };
 
-bool fir_plan(int in_kind, int M, int n_out, FirParams &P);
+bool fir_plan(int in_kind, int M, int n_out, FirParams &P, bool allow_stream = true);
 hipError_t launch_fir_tile(const FirParams &P, int in_kind, hipStream_t s);
 hipError_t launch_fir_stats_finish(const double *stats, int nchunk, int B, double *std_out, double *inv_out,
                                    hipStream_t s);

@@ -15,6 +15,7 @@
 // chunk) partial statistics (count, mean, M2) are merged by fir_stats_finish
 // with Chan's formula -> 1/std per burst, applied by the consumer kernels.
 #include "dsp_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -34,47 +35,15 @@ __device__ __forceinline__ d2v to_stage(d2v v, float) { return v; }
 __device__ __forceinline__ void put(f2v *p, double re, double im) { *p = f2v{(float)re, (float)im}; }
 __device__ __forceinline__ void put(d2v *p, double re, double im) { *p = d2v{re, im}; }
 
-// NW waves per workgroup (4 or 8): each stages 64 / NW rows and computes CH / NW outputs per lane
-template <typename IN, typename OUT, int OG, int KS, int NW>
-__global__ __launch_bounds__(64 * NW) void fir_tile_kernel(FirParams P)
+// Stage the input windows of one tile: xs[bb][i] = x[b][x0 + i], i < W, zero outside the burst (or the
+// stream).  W <= 64 * KS, so a wave covers a row in KS steps; all loads of a wave are issued before
+// the first LDS write (each wave would otherwise pay the HBM latency once per load).
+template <typename IN, int KS, int NW>
+__device__ __forceinline__ void stage_windows(const FirParams &P, typename Stage<IN>::T *xs, int tile, int x0, int W,
+                                              int stride, float isc, int lane, int w)
 {
     typedef typename Stage<IN>::T ST;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int M = P.M, CH = P.CH, W = P.W, stride = P.stride;
-    const int m8 = (M + 7) & ~7;
-    double *hrev = (double *)smem;                                  // [m8] reversed taps, zero padded
-    ST *xs = (ST *)(smem + (size_t)m8 * 8);                         // [64][stride]
-    double *red = (double *)xs;                                     // [4][64][4] reduction scratch, reuses xs
-
-    const int tile = blockIdx.y, chunk = blockIdx.x;
-    const int n0 = chunk * CH;
-    if (tile > 0 && n0 + CH <= P.skip_rows) {           // rows another kernel fills (segment-parallel mode):
-        const int sb = tile * 64 + (int)threadIdx.x;    // leave empty statistics records behind
-        if (P.stats && threadIdx.x < 64 && sb < P.B) {
-            double *st = P.stats + ((size_t)sb * P.nchunk + chunk) * 4;
-            st[0] = 0.0; st[1] = 0.0; st[2] = 0.0; st[3] = 0.0;
-        }
-        // the predecessors' workgroups store these rows (feed_lead); the idle lanes of the last tile
-        // have no predecessor: clear them (the recurrence kernel loads whole rows)
-        const int idle0 = P.B - tile * 64;
-        if (P.feed_lead && P.dst && idle0 < 64) {
-            OUT *d = (OUT *)P.dst + (size_t)tile * P.rows * 64;
-            for (int i = threadIdx.x; i < CH * 64; i += 64 * NW) {
-                const int r = n0 + (i >> 6), l = i & 63;
-                if (l >= idle0 && r < P.rows) put(d + (size_t)r * 64 + l, 0.0, 0.0);
-            }
-        }
-        return;
-    }
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     constexpr int RQ = 64 / NW;                        // rows a wave stages
-    const float isc = P.in_scale ? *P.in_scale : 1.0f;
-
-    for (int i = threadIdx.x; i < m8; i += 64 * NW) hrev[i] = i < M ? P.h[M - 1 - i] : 0.0;
-    // stage the input windows: xs[bb][i] = x[b][n0 + start - (M-1) + i], zero outside the burst.
-    // W <= 64 * KS (launch_fir_tile_t), so a wave covers a row in KS steps; all 16 * KS loads of a wave are
-    // issued before the first LDS write (each wave would otherwise pay the HBM latency once per load).
-    const int x0 = n0 + P.start - (M - 1);
     // Interior chunks of full tiles need no bounds logic at all (it is half of the kernel's instructions
     // otherwise): every staged index of all 64 rows lies inside its burst, or inside the stream (window
     // starts do not decrease with the window number).
@@ -143,118 +112,317 @@ __global__ __launch_bounds__(64 * NW) void fir_tile_kernel(FirParams P)
             }
         }
     }
+}
+
+// What a lane (= burst) does with the outputs it has computed: statistics in one pass, the tile store,
+// and in the segment-parallel mode the second store into the successor window's warm-up rows.
+template <typename OUT>
+struct LaneOut {
+    int len, st_lo, st_hi, rows, feed_lo, feed_hi, feed_lead;
+    double scale;
+    OUT *dst, *feed;
+    // statistics of this lane's counted outputs: sums of (y - c) and |y - c|^2 around the first counted
+    // output c (a sample of the data, so the usual cancellation of the sum-of-squares form cannot
+    // occur, whatever the signal's offset)
+    double s_re, s_im, s_sq, c_re, c_im;
+    int cnt;
+
+    __device__ __forceinline__ void init(const FirParams &P, int tile, int lane)
+    {
+        const int b = tile * 64 + lane;
+        len = b < P.B ? (P.lens ? P.lens[b] : P.len_all) : 0;
+        scale = (P.scale && b < P.B) ? P.scale[b] : 1.0;
+        st_lo = (P.stat_lo && b < P.B) ? P.stat_lo[b] : 0;
+        st_hi = (P.stat_hi && b < P.B) ? P.stat_hi[b] : len;
+        rows = P.rows;
+        dst = P.dst ? (OUT *)P.dst + (size_t)tile * P.rows * 64 + lane : nullptr;
+        // segment-parallel mode: this window's rows [shift, shift + skip_rows) are the warm-up rows
+        // [0, skip_rows) of its successor (the same samples, hence the same sums): store them there too
+        feed = nullptr;
+        feed_lo = 0;
+        feed_lead = P.feed_lead;
+        if (P.feed_lead && P.dst && b + 1 < P.B && b + 1 >= 64) {
+            feed_lo = (int)(P.starts[b + 1] - P.starts[b]);
+            feed = (OUT *)P.dst + (size_t)((b + 1) >> 6) * P.rows * 64 + ((b + 1) & 63) - (ptrdiff_t)feed_lo * 64;
+        }
+        feed_hi = feed_lo + P.skip_rows;
+        s_re = 0.0; s_im = 0.0; s_sq = 0.0; c_re = 0.0; c_im = 0.0;
+        cnt = 0;
+    }
+
+    // outputs n_a .. n_a + OG - 1 of this lane's burst
+    template <int OG>
+    __device__ __forceinline__ void block(int n_a, const double (&are)[OG], const double (&aim)[OG])
+    {
+#pragma unroll
+        for (int o = 0; o < OG; o++) {
+            const int n = n_a + o;
+            const bool valid = n < len;
+            const bool counts = valid && n >= st_lo && n < st_hi;
+            if (counts) {
+                if (cnt == 0) { c_re = are[o]; c_im = aim[o]; }
+                const double dr = are[o] - c_re, di = aim[o] - c_im;
+                s_re += dr; s_im += di; s_sq += dr * dr + di * di;
+                cnt++;
+            }
+            if (dst && n < rows) put(dst + (size_t)n * 64, valid ? are[o] * scale : 0.0, valid ? aim[o] * scale : 0.0);
+        }
+        if (feed_lead) {
+            // a branch per output costs more than the store: groups wholly inside every lane's
+            // range (the usual case, ranges and groups are multiples of OG) store unconditionally
+            const int n_z = n_a + OG - 1;
+            const bool in_all = feed && n_a >= feed_lo && n_z < feed_hi;
+            const bool in_any = feed && n_z >= feed_lo && n_a < feed_hi;
+            if (__all(in_all)) {
+#pragma unroll
+                for (int o = 0; o < OG; o++) {
+                    const bool valid = n_a + o < len;
+                    put(feed + (ptrdiff_t)(n_a + o) * 64, valid ? are[o] * scale : 0.0, valid ? aim[o] * scale : 0.0);
+                }
+            } else if (__any(in_any)) {
+#pragma unroll
+                for (int o = 0; o < OG; o++) {
+                    const int n = n_a + o;
+                    const bool valid = n < len;
+                    if (feed && n >= feed_lo && n < feed_hi)
+                        put(feed + (ptrdiff_t)n * 64, valid ? are[o] * scale : 0.0, valid ? aim[o] * scale : 0.0);
+                }
+            }
+        }
+    }
+
+    // The same for a block every lane of the wave keeps whole: all OG outputs valid, counted and inside
+    // the tile's rows, no second store (interior chunks of equal-length bursts) -- no predicates at all.
+    template <int OG, bool SCALED>
+    __device__ __forceinline__ void block_plain(int n_a, const double (&are)[OG], const double (&aim)[OG])
+    {
+        if (cnt == 0) { c_re = are[0]; c_im = aim[0]; }
+#pragma unroll
+        for (int o = 0; o < OG; o++) {
+            const double dr = are[o] - c_re, di = aim[o] - c_im;
+            s_re += dr; s_im += di; s_sq += dr * dr + di * di;
+            if (dst) put(dst + (size_t)(n_a + o) * 64, SCALED ? are[o] * scale : are[o], SCALED ? aim[o] * scale : aim[o]);
+        }
+        cnt += OG;
+    }
+
+    // per (burst, chunk) statistics: each wave's (n, mean, M2), merged over the NW waves (Chan)
+    template <int NW>
+    __device__ __forceinline__ void reduce_stats(const FirParams &P, double *red, int tile, int chunk, int lane, int w)
+    {
+        __syncthreads();                    // every wave is done with xs: reuse it as scratch
+        {
+            const double n = (double)cnt;
+            const double mr = cnt ? s_re / n : 0.0, mi = cnt ? s_im / n : 0.0;     // mean of (y - c)
+            red[(w * 64 + lane) * 4 + 0] = n;
+            red[(w * 64 + lane) * 4 + 1] = c_re + mr;
+            red[(w * 64 + lane) * 4 + 2] = c_im + mi;
+            red[(w * 64 + lane) * 4 + 3] = cnt ? s_sq - n * (mr * mr + mi * mi) : 0.0;
+        }
+        __syncthreads();
+        const int b = tile * 64 + lane;
+        if (w == 0 && b < P.B) {
+            double t_n = 0.0, m_re = 0.0, m_im = 0.0, t_m2 = 0.0;
+            for (int q = 0; q < NW; q++) {
+                const double *r = red + (q * 64 + lane) * 4;
+                const double nb = r[0];
+                if (nb <= 0.0) continue;
+                const double nn = t_n + nb, dr = r[1] - m_re, di = r[2] - m_im;
+                t_m2 += r[3] + (dr * dr + di * di) * (t_n * nb / nn);
+                m_re += dr * (nb / nn);
+                m_im += di * (nb / nn);
+                t_n = nn;
+            }
+            if (t_m2 < 0.0) t_m2 = 0.0;
+            double *st = P.stats + ((size_t)b * P.nchunk + chunk) * 4;
+            st[0] = t_n; st[1] = m_re; st[2] = m_im; st[3] = t_m2;
+        }
+    }
+};
+
+// rows of a tile that another workgroup fills (segment-parallel mode, skip_rows): leave empty statistics
+// records behind and clear the idle lanes of the last tile
+template <typename OUT, int NT>
+__device__ __forceinline__ void skipped_chunk(const FirParams &P, int tile, int chunk, int n0, int CH)
+{
+    const int sb = tile * 64 + (int)threadIdx.x;
+    if (P.stats && threadIdx.x < 64 && sb < P.B) {
+        double *st = P.stats + ((size_t)sb * P.nchunk + chunk) * 4;
+        st[0] = 0.0; st[1] = 0.0; st[2] = 0.0; st[3] = 0.0;
+    }
+    // the predecessors' workgroups store these rows (feed_lead); the idle lanes of the last tile
+    // have no predecessor: clear them (the recurrence kernel loads whole rows)
+    const int idle0 = P.B - tile * 64;
+    if (P.feed_lead && P.dst && idle0 < 64) {
+        OUT *d = (OUT *)P.dst + (size_t)tile * P.rows * 64;
+        for (int i = threadIdx.x; i < CH * 64; i += NT) {
+            const int r = n0 + (i >> 6), l = i & 63;
+            if (l >= idle0 && r < P.rows) put(d + (size_t)r * 64 + l, 0.0, 0.0);
+        }
+    }
+}
+
+// NW waves per workgroup (4 or 8): each stages 64 / NW rows and computes CH / NW outputs per lane
+template <typename IN, typename OUT, int OG, int KS, int NW>
+__global__ __launch_bounds__(64 * NW) void fir_tile_kernel(FirParams P)
+{
+    typedef typename Stage<IN>::T ST;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int M = P.M, CH = P.CH, W = P.W, stride = P.stride;
+    const int m8 = (M + 7) & ~7;
+    double *hrev = (double *)smem;                                  // [m8] reversed taps, zero padded
+    ST *xs = (ST *)(smem + (size_t)m8 * 8);                         // [64][stride]
+    double *red = (double *)xs;                                     // [4][64][4] reduction scratch, reuses xs
+
+    const int tile = blockIdx.y, chunk = blockIdx.x;
+    const int n0 = chunk * CH;
+    if (tile > 0 && n0 + CH <= P.skip_rows) {           // rows another kernel fills (segment-parallel mode)
+        skipped_chunk<OUT, 64 * NW>(P, tile, chunk, n0, CH);
+        return;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float isc = P.in_scale ? *P.in_scale : 1.0f;
+
+    for (int i = threadIdx.x; i < m8; i += 64 * NW) hrev[i] = i < M ? P.h[M - 1 - i] : 0.0;
+    const int x0 = n0 + P.start - (M - 1);
+    stage_windows<IN, KS, NW>(P, xs, tile, x0, W, stride, isc, lane, w);
     __syncthreads();
 
-    // lane = burst; this wave computes outputs [w*CH/4, (w+1)*CH/4) of the chunk, OG at a time
-    const int b = tile * 64 + lane;
-    const int len = b < P.B ? (P.lens ? P.lens[b] : P.len_all) : 0;
-    const double scale = (P.scale && b < P.B) ? P.scale[b] : 1.0;
-    const int st_lo = (P.stat_lo && b < P.B) ? P.stat_lo[b] : 0;
-    const int st_hi = (P.stat_hi && b < P.B) ? P.stat_hi[b] : len;
+    // lane = burst; this wave computes outputs [w*CH/NW, (w+1)*CH/NW) of the chunk, OG at a time
+    LaneOut<OUT> lo;
+    lo.init(P, tile, lane);
     const ST *xrow = xs + (size_t)lane * stride;
-    OUT *dst = P.dst ? (OUT *)P.dst + (size_t)tile * P.rows * 64 + lane : nullptr;
-    // segment-parallel mode: this window's rows [shift, shift + skip_rows) are the warm-up rows
-    // [0, skip_rows) of its successor (the same samples, hence the same sums): store them there too
-    OUT *feed = nullptr;
-    int feed_lo = 0;
-    if (P.feed_lead && P.dst && b + 1 < P.B && b + 1 >= 64) {
-        feed_lo = (int)(P.starts[b + 1] - P.starts[b]);
-        feed = (OUT *)P.dst + (size_t)((b + 1) >> 6) * P.rows * 64 + ((b + 1) & 63) - (ptrdiff_t)feed_lo * 64;
-    }
-    const int feed_hi = feed_lo + P.skip_rows;
     const int per_wave = CH / NW;
-    // statistics of this lane's counted outputs in one pass: sums of (y - c) and |y - c|^2 around the
-    // first counted output c (a sample of the data, so the usual cancellation of the sum-of-squares
-    // form cannot occur, whatever the signal's offset)
-    double s_re = 0.0, s_im = 0.0, s_sq = 0.0, c_re = 0.0, c_im = 0.0;
-    int cnt = 0;
 #pragma unroll 1
     for (int g = 0; g * OG < per_wave; g++) {
-        {
-            const int o0 = w * per_wave + g * OG;
-            double are[OG], aim[OG];
+        const int o0 = w * per_wave + g * OG;
+        double are[OG], aim[OG];
 #pragma unroll
-            for (int o = 0; o < OG; o++) { are[o] = 0.0; aim[o] = 0.0; }
-            for (int i0 = 0; i0 < M; i0 += 8) {
-                ST xw[OG + 7];
+        for (int o = 0; o < OG; o++) { are[o] = 0.0; aim[o] = 0.0; }
+        for (int i0 = 0; i0 < M; i0 += 8) {
+            ST xw[OG + 7];
 #pragma unroll
-                for (int j = 0; j < OG + 7; j++) xw[j] = xrow[o0 + i0 + j];
+            for (int j = 0; j < OG + 7; j++) xw[j] = xrow[o0 + i0 + j];
 #pragma unroll
-                for (int ii = 0; ii < 8; ii++) {
-                    const double hv = hrev[i0 + ii];
+            for (int ii = 0; ii < 8; ii++) {
+                const double hv = hrev[i0 + ii];
 #pragma unroll
-                    for (int o = 0; o < OG; o++) {
-                        are[o] = __builtin_fma(hv, (double)xw[o + ii].x, are[o]);
-                        aim[o] = __builtin_fma(hv, (double)xw[o + ii].y, aim[o]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int o = 0; o < OG; o++) {
-                const int n = n0 + o0 + o;
-                const bool valid = n < len;
-                const bool counts = valid && n >= st_lo && n < st_hi;
-                if (counts) {
-                    if (cnt == 0) { c_re = are[o]; c_im = aim[o]; }
-                    const double dr = are[o] - c_re, di = aim[o] - c_im;
-                    s_re += dr; s_im += di; s_sq += dr * dr + di * di;
-                    cnt++;
-                }
-                if (dst && n < P.rows) put(dst + (size_t)n * 64, valid ? are[o] * scale : 0.0,
-                                           valid ? aim[o] * scale : 0.0);
-            }
-            if (P.feed_lead) {
-                // a branch per output costs more than the store: groups wholly inside every lane's
-                // range (the usual case, ranges and groups are multiples of OG) store unconditionally
-                const int n_a = n0 + o0, n_z = n_a + OG - 1;
-                const bool in_all = feed && n_a >= feed_lo && n_z < feed_hi;
-                const bool in_any = feed && n_z >= feed_lo && n_a < feed_hi;
-                if (__all(in_all)) {
-#pragma unroll
-                    for (int o = 0; o < OG; o++) {
-                        const bool valid = n_a + o < len;
-                        put(feed + (ptrdiff_t)(n_a + o) * 64, valid ? are[o] * scale : 0.0, valid ? aim[o] * scale : 0.0);
-                    }
-                } else if (__any(in_any)) {
-#pragma unroll
-                    for (int o = 0; o < OG; o++) {
-                        const int n = n_a + o;
-                        const bool valid = n < len;
-                        if (feed && n >= feed_lo && n < feed_hi)
-                            put(feed + (ptrdiff_t)n * 64, valid ? are[o] * scale : 0.0, valid ? aim[o] * scale : 0.0);
-                    }
+                for (int o = 0; o < OG; o++) {
+                    are[o] = __builtin_fma(hv, (double)xw[o + ii].x, are[o]);
+                    aim[o] = __builtin_fma(hv, (double)xw[o + ii].y, aim[o]);
                 }
             }
         }
+        lo.template block<OG>(n0 + o0, are, aim);
     }
-    if (!P.stats) return;
-    // ---- per (burst, chunk) statistics: each wave's (n, mean, M2), merged over the four waves (Chan) ----
-    __syncthreads();                    // every wave is done with xs: reuse it as scratch
-    {
-        const double n = (double)cnt;
-        const double mr = cnt ? s_re / n : 0.0, mi = cnt ? s_im / n : 0.0;     // mean of (y - c)
-        red[(w * 64 + lane) * 4 + 0] = n;
-        red[(w * 64 + lane) * 4 + 1] = c_re + mr;
-        red[(w * 64 + lane) * 4 + 2] = c_im + mi;
-        red[(w * 64 + lane) * 4 + 3] = cnt ? s_sq - n * (mr * mr + mi * mi) : 0.0;
+    if (P.stats) lo.template reduce_stats<NW>(P, red, tile, chunk, lane, w);
+}
+
+// ---------------------------------------------------------------------------
+// fir_stream_kernel: the matched filter for filters of up to FIR_MT taps on float32 staging (complex64
+// or int16 input) -- the RRC of every reference call site (41 taps at sps 4, span 10).
+// Same tile / chunk decomposition, same staging and the same outputs, bit for bit, as fir_tile_kernel;
+// what differs is how a wave turns its window into outputs:
+//   * the taps never touch LDS or VGPRs: they are wave-uniform, read with scalar loads (constant
+//     address space: the buffer is written by fir_pad_taps_k before this launch and by nobody during
+//     it) and used straight out of SGPRs as the multiplier of v_fmac_f64;
+//   * a lane (= burst) streams its OG + FIR_MT - 1 window samples out of LDS ONCE, in order, widens each
+//     to float64 once and adds it into every output it belongs to: OG * 82 FMAs for OG outputs with
+//     2 * (OG + 40) conversions and (OG + 40) / 2 LDS reads (the tap-blocked loop of fir_tile_kernel
+//     pays 26 conversions, 13 sample reads and 8 tap reads per 96 FMAs, and pads 41 taps to 48);
+//   * the loop over the window is fully unrolled in groups of FIR_GS samples; the group's accumulators
+//     pass through an empty asm so that the compiler keeps the groups in order (left alone it hoists
+//     all loads and conversions to the top and needs 220 VGPRs).
+// Each output's sum runs over the samples in ascending order, as in fir_tile_kernel.
+constexpr int FIR_STREAM_OG = 14;   // outputs per lane and wave of the stream kernel (chunk = 8 waves x 14 = 112)
+constexpr int FIR_MT = 41;      // taps the stream kernel is unrolled for (shorter filters are zero padded)
+constexpr int FIR_GS = 4;       // window samples per scheduling group
+
+typedef const __attribute__((address_space(4))) double *cdbl_ptr;     // constant address space: scalar loads
+
+__global__ void fir_pad_taps_k(const double *__restrict__ h, int M, double *__restrict__ out)
+{
+    const int i = threadIdx.x;
+    if (i < FIR_MT) out[i] = i < M ? h[i] : 0.0;
+}
+
+template <typename IN, typename OUT, int OG, int KS, int NW>
+__global__ __launch_bounds__(64 * NW) void fir_stream_kernel(FirParams P)
+{
+    typedef typename Stage<IN>::T ST;
+    static_assert(sizeof(ST) == 8, "float32 staging");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int CH = OG * NW, W = CH + FIR_MT - 1;
+    const int stride = P.stride;
+    ST *xs = (ST *)smem;                                            // [64][stride]
+    double *red = (double *)xs;                                     // [NW][64][4] reduction scratch, reuses xs
+
+    const int tile = blockIdx.y, chunk = blockIdx.x;
+    const int n0 = chunk * CH;
+    if (tile > 0 && n0 + CH <= P.skip_rows) {           // rows another workgroup fills (segment-parallel mode)
+        skipped_chunk<OUT, 64 * NW>(P, tile, chunk, n0, CH);
+        return;
     }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float isc = P.in_scale ? *P.in_scale : 1.0f;
+    // the filter as FIR_MT taps, zeros appended: y[n] = sum_{j < FIR_MT} h[j] x[n + start - j]
+    const int x0 = n0 + P.start - (FIR_MT - 1);
+    stage_windows<IN, KS, NW>(P, xs, tile, x0, W, stride, isc, lane, w);
     __syncthreads();
-    if (w == 0 && b < P.B) {
-        double t_n = 0.0, m_re = 0.0, m_im = 0.0, t_m2 = 0.0;
-        for (int q = 0; q < NW; q++) {
-            const double *r = red + (q * 64 + lane) * 4;
-            const double nb = r[0];
-            if (nb <= 0.0) continue;
-            const double nn = t_n + nb, dr = r[1] - m_re, di = r[2] - m_im;
-            t_m2 += r[3] + (dr * dr + di * di) * (t_n * nb / nn);
-            m_re += dr * (nb / nn);
-            m_im += di * (nb / nn);
-            t_n = nn;
+
+    LaneOut<OUT> lo;
+    lo.init(P, tile, lane);
+    cdbl_ptr hp = (cdbl_ptr)P.h_pad;
+    int off = lane * stride + w * OG;                   // this lane's first window sample
+    double are[OG], aim[OG];
+#pragma unroll
+    for (int o = 0; o < OG; o++) { are[o] = 0.0; aim[o] = 0.0; }
+    constexpr int NS = OG + FIR_MT - 1;                 // window samples of a block of OG outputs
+    constexpr int NG = (NS + FIR_GS - 1) / FIR_GS;
+    ST cur[FIR_GS], nxt[FIR_GS];
+#pragma unroll
+    for (int q = 0; q < FIR_GS; q++) cur[q] = xs[off + q];
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        if (g + 1 < NG) {
+#pragma unroll
+            for (int q = 0; q < FIR_GS; q++)
+                if ((g + 1) * FIR_GS + q < NS) nxt[q] = xs[off + (g + 1) * FIR_GS + q];
         }
-        if (t_m2 < 0.0) t_m2 = 0.0;
-        double *st = P.stats + ((size_t)b * P.nchunk + chunk) * 4;
-        st[0] = t_n; st[1] = m_re; st[2] = m_im; st[3] = t_m2;
+#pragma unroll
+        for (int q = 0; q < FIR_GS; q++) {
+            const int s = g * FIR_GS + q;
+            if (s < NS) {
+                const double xr = (double)cur[q].x, xi = (double)cur[q].y;
+#pragma unroll
+                for (int o = 0; o < OG; o++) {
+                    const int j = s - o;            // window sample s = x[n_o + start - (FIR_MT-1) + j]: tap FIR_MT-1-j
+                    if (j >= 0 && j < FIR_MT) {
+                        const double t = hp[FIR_MT - 1 - j];
+                        are[o] = __builtin_fma(t, xr, are[o]);
+                        aim[o] = __builtin_fma(t, xi, aim[o]);
+                    }
+                }
+            }
+        }
+        // keep the groups in program order (see the header)
+#pragma unroll
+        for (int o = 0; o < OG; o++) asm volatile("" : "+v"(are[o]), "+v"(aim[o]));
+        asm volatile("" : "+v"(off));
+#pragma unroll
+        for (int q = 0; q < FIR_GS; q++) cur[q] = nxt[q];
     }
+    const int n_a = n0 + w * OG;
+    // interior chunk of equal-length bursts, every output kept, counted and stored once: no predicates
+    const bool plain = tile * 64 + 63 < P.B && !P.lens && !P.stat_lo && !P.feed_lead && n0 + CH <= P.len_all &&
+                       n0 + CH <= P.rows;
+    if (plain) {
+        if (P.scale) lo.template block_plain<OG, true>(n_a, are, aim);
+        else lo.template block_plain<OG, false>(n_a, are, aim);
+    } else {
+        lo.template block<OG>(n_a, are, aim);
+    }
+    if (P.stats) lo.template reduce_stats<NW>(P, red, tile, chunk, lane, w);
 }
 
 // merge the chunk statistics of each burst (Chan et al.) -> std and 1/std
@@ -479,6 +647,25 @@ __global__ void iq_i16_convert_kernel(const s2v *__restrict__ raw, int64_t n, co
         out[i] = f2v{(float)raw[i].x * s, (float)raw[i].y * s};
 }
 
+template <typename IN, typename OUT>
+hipError_t launch_fir_stream_t(const FirParams &P, hipStream_t s)
+{
+    constexpr int OG = FIR_STREAM_OG, NW = 8, CH = OG * NW, W = CH + FIR_MT - 1, KS = (W + 63) / 64;
+    if (P.CH != CH || P.W != W || !P.h_pad) return hipErrorInvalidValue;
+    const int ntiles = (P.B + 63) / 64;
+    size_t lds = (size_t)64 * P.stride * 8;
+    if (lds < (size_t)NW * 64 * 4 * 8) lds = (size_t)NW * 64 * 4 * 8;              // the statistics scratch
+    hipLaunchKernelGGL(fir_pad_taps_k, dim3(1), dim3(64), 0, s, P.h, P.M, P.h_pad);
+    void (*k)(FirParams) = fir_stream_kernel<IN, OUT, OG, KS, NW>;
+    if (getenv("DSP_FIR_LDS_PAD")) lds += atoi(getenv("DSP_FIR_LDS_PAD"));   // experiment: workgroups per CU
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, dim3(P.nchunk, ntiles), dim3(64 * NW), lds, s, P);
+    return hipGetLastError();
+}
+
 template <typename IN, typename OUT, int OG, int OG8>
 hipError_t launch_fir_tile_t(const FirParams &P, hipStream_t s)
 {
@@ -506,8 +693,16 @@ hipError_t launch_fir_tile_t(const FirParams &P, hipStream_t s)
 }  // namespace
 
 // choose the chunk geometry; returns false if the filter is too long for the LDS-tiled kernel
-bool fir_plan(int in_kind, int M, int n_out, FirParams &P)
+bool fir_plan(int in_kind, int M, int n_out, FirParams &P, bool allow_stream)
 {
+    P.stream = 0;
+    if (in_kind != DSP_IN_C128 && M <= FIR_MT && allow_stream) {
+        // the stream kernel (fir_stream_kernel): 8 waves x FIR_STREAM_OG outputs per chunk
+        P.stream = 1;
+        P.CH = FIR_STREAM_OG * 8; P.W = P.CH + FIR_MT - 1; P.stride = P.W | 1;
+        P.nchunk = (n_out + P.CH - 1) / P.CH;
+        return true;
+    }
     const int elem = in_kind == DSP_IN_C128 ? 16 : 8;
     const int og = in_kind == DSP_IN_C128 ? 4 : 8;
     if (M > 4096) return false;
@@ -528,6 +723,12 @@ bool fir_plan(int in_kind, int M, int n_out, FirParams &P)
 
 hipError_t launch_fir_tile(const FirParams &P, int in_kind, hipStream_t s)
 {
+    if (P.stream) {
+        // the start of the zero-padded filter moves with the padding: none here (zeros are appended)
+        if (in_kind == DSP_IN_I16) return launch_fir_stream_t<s2v, f2v>(P, s);
+        if (in_kind == DSP_IN_C64) return launch_fir_stream_t<f2v, f2v>(P, s);
+        return hipErrorInvalidValue;
+    }
     switch (in_kind) {
         case DSP_IN_I16: return launch_fir_tile_t<s2v, f2v, 8, 6>(P, s);
         case DSP_IN_C64: return launch_fir_tile_t<f2v, f2v, 8, 6>(P, s);
