@@ -24,7 +24,8 @@ struct dsp_ctx {
     int lead_copy;      // segment-parallel mode, warm-up rows: 0 = the filter's second store, 1 = seg_lead_copy_k, 2 = filtered per window
     int spare_wave;     // split kernel, idle waves for SIMD balance: -1 auto, 0 never, 1 three waves, 2 four waves + CU tickets
     unsigned *cu_tickets;   // [4096] per-CU workgroup counters for the four-wave launch
-    int fir_stream;     // matched filter of <= 41 taps: 1 = fir_stream_kernel (default), 0 = the tap-blocked kernel
+    int fir_stream;     // matched filter of <= 41 taps: 2 = persistent fir_strip_kernel where eligible (default),
+                        // 1 = fir_stream_kernel, 0 = the tap-blocked kernel
     double *fir_taps;   // [64] the stream kernel's zero-padded taps
     int prio_period;    // split kernel: priority rotation period in DMA blocks (power of two), 0 = off
     // grow-only device scratch kept between calls of the segment-parallel mode (its window tiles are
@@ -134,7 +135,7 @@ int dsp_create(int device_id, dsp_ctx **out)
     c->prio_period = 0;
     c->spare_wave = -1;
     c->lead_copy = 0;
-    c->fir_stream = 1;
+    c->fir_stream = 2;
     c->fir_taps = nullptr;
 #ifdef DSP_TRACE
     c->trace = nullptr;
@@ -236,7 +237,7 @@ int dsp_set_option(dsp_ctx *c, const char *name, int64_t value)
         c->trace_stamps = (int)value;
 #endif
     } else if (!strcmp(name, "fir_stream")) {
-        if (value < 0 || value > 1) return fail(DSP_E_ARG, "fir_stream must be 0 or 1");
+        if (value < 0 || value > 2) return fail(DSP_E_ARG, "fir_stream must be 0, 1 or 2");
         c->fir_stream = (int)value;
     } else if (!strcmp(name, "lead_copy")) {
         if (value < 0 || value > 2) return fail(DSP_E_ARG, "lead_copy must be 0, 1 or 2");
@@ -660,7 +661,7 @@ int64_t dsp_fir_workspace_bytes(int in_kind, int64_t B, int64_t N, int n_taps)
     FirParams P, Q;
     if (n_taps < 1 || !fir_plan(in_kind, n_taps, (int)N, P, false)) return 0;
     fir_plan(in_kind, n_taps, (int)N, Q, true);          // either kernel's chunking fits
-    return (int64_t)B * (P.nchunk > Q.nchunk ? P.nchunk : Q.nchunk) * 4 * 8;
+    return (int64_t)B * ((P.nchunk > Q.nchunk ? P.nchunk : Q.nchunk) + 8) * 4 * 8;     // + 8: fir_plan_strips
 }
 
 int dsp_fir_tiles_dev(dsp_ctx *c, const dsp_fir_args *a)
@@ -675,10 +676,10 @@ int dsp_fir_tiles_dev(dsp_ctx *c, const dsp_fir_args *a)
     memset(&P, 0, sizeof(P));
     if (!fir_plan(a->in_kind, a->n_taps, (int)a->N, P, c->fir_stream != 0))
         return fail(DSP_E_ARG, "fir: %d taps are too many for the LDS-tiled kernel", a->n_taps);
-    P.h_pad = c->fir_taps;
+    P.h_pad = c->fir_taps; P.strip_ok = c->fir_stream == 2; P.n_cu = c->n_cu;
     const bool want_std = a->std_out || a->inv_std_out;
-    if (want_std && (!a->workspace || a->workspace_bytes < (int64_t)a->B * P.nchunk * 32))
-        return fail(DSP_E_ARG, "fir: workspace too small (need %lld bytes)", (long long)a->B * P.nchunk * 32);
+    if (want_std && (!a->workspace || a->workspace_bytes < (int64_t)a->B * (P.nchunk + 8) * 32))
+        return fail(DSP_E_ARG, "fir: workspace too small (need %lld bytes)", (long long)a->B * (P.nchunk + 8) * 32);
     P.src = a->src; P.ld = a->src_stride; P.lens = a->lens; P.len_all = (int)a->N; P.B = (int)a->B;
     P.h = a->h; P.M = a->n_taps; P.start = a->start < 0 ? (a->n_taps - 1) / 2 : a->start;
     P.in_scale = a->in_scale; P.dst = a->tiles; P.rows = (int)a->rows; P.scale = a->scale;
@@ -686,7 +687,7 @@ int dsp_fir_tiles_dev(dsp_ctx *c, const dsp_fir_args *a)
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(launch_fir_tile(P, a->in_kind, c->stream));
     if (want_std)
-        HIP_TRY(launch_fir_stats_finish(P.stats, P.nchunk, P.B, a->std_out, a->inv_std_out, c->stream));
+        HIP_TRY(launch_fir_stats_finish(P, a->std_out, a->inv_std_out, c->stream));
     return DSP_OK;
 }
 
@@ -1380,7 +1381,7 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
         HIP_TRY(launch_fir_tile(Q, a->in_kind, st));
         if (share_lead && c->lead_copy == 1)                      // ... or a copy kernel does afterwards
             HIP_TRY(launch_seg_lead_copy(d_tiles.p, (int)rows, d_starts.as<int64_t>(), S, (int)lead, st));
-        HIP_TRY(launch_fir_stats_global(Q.stats, (int64_t)S * Q.nchunk, S, nullptr, d_inv.as<double>(),
+        HIP_TRY(launch_fir_stats_global(Q.stats, (int64_t)S * Q.nrec, S, nullptr, d_inv.as<double>(),
                                         d_part.as<double>(), 1024, st));
         d_scale = d_inv.as<double>();
     } else {

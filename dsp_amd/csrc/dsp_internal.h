@@ -92,15 +92,23 @@ struct FirParams {
     int skip_rows;            // tiles > 0 skip the chunks that end at or before this output row (0 = none)
     int waves;                // waves per workgroup: 0 = auto (8 where the chunk divides), 4 = always 4
     int stream;               // set by fir_plan: 1 = fir_stream_kernel (<= 41 taps, float32 staging)
+    int strip_ok;             // in: launch_fir_tile may use the persistent fir_strip_kernel
+    int n_cu;                 // in: compute units of the device (strip planning)
+    // set by launch_fir_tile:
+    int cps;                  // chunks per strip of fir_strip_kernel, 0 = chunk-per-workgroup kernels only
+    int c_int0, c_int1;       // interior chunks [c_int0, c_int1) the strips cover (of the first strip_tiles tiles)
+    int strip_tiles;          // full tiles
+    int nrec;                 // statistics records per burst in the workspace (stride)
+    int rec_full;             // records written for the bursts of the first strip_tiles tiles (the others: nchunk)
+    int edge, rec0, tile0;    // fir_stream_kernel beside the strips: edge-chunk mapping, first record, first tile
     double *h_pad;            // device scratch for the stream kernel's zero-padded taps (>= 48 doubles)
     int feed_lead;            // 1: every window also stores its rows [shift, shift + skip_rows) as rows [0, skip_rows)
                               //    of its successor (shift = starts[b+1] - starts[b]; successors in tiles > 0 only)
 };
 
 bool fir_plan(int in_kind, int M, int n_out, FirParams &P, bool allow_stream = true);
-hipError_t launch_fir_tile(const FirParams &P, int in_kind, hipStream_t s);
-hipError_t launch_fir_stats_finish(const double *stats, int nchunk, int B, double *std_out, double *inv_out,
-                                   hipStream_t s);
+hipError_t launch_fir_tile(FirParams &P, int in_kind, hipStream_t s);
+hipError_t launch_fir_stats_finish(const FirParams &P, double *std_out, double *inv_out, hipStream_t s);
 hipError_t launch_fir_stats_global(const double *stats, int64_t count, int B, double *std_out, double *inv_fill,
                                    double *partial, int n_partial, hipStream_t s);
 hipError_t launch_fir_direct(const FirParams &P, int in_kind, void *dst, int64_t dst_ld, int n_out, hipStream_t s);
