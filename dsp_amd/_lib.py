@@ -138,6 +138,8 @@ def _declare(L):
     L.dsp_fir_workspace_bytes.argtypes = [ci, i64, i64, ci]
     L.dsp_fir_workspace_bytes.restype = i64
     L.dsp_fir_tiles_dev.argtypes = [vp, C.POINTER(FirArgs)]
+    L.dsp_fir_tiles_static_dev.argtypes = [vp, C.POINTER(FirArgs)]
+    L.dsp_static_scratch_bytes.restype = i64
     L.dsp_synth_bursts_dev.argtypes = [vp, C.c_uint64, i64, i64, ci, ci, vp, ci, dbl, vp]
     L.dsp_synth_stream_dev.argtypes = [vp, C.c_uint64, i64, ci, vp, ci, dbl, dbl, dbl, dbl, ci, dbl, vp]
     L.dsp_diff_corr.argtypes = [vp, vp, ci, i64, vp, ci, ci, vp, i64]
@@ -163,7 +165,7 @@ def _declare(L):
                  "dsp_fir_same_std", "dsp_rx_chain", "dsp_fir_tiles_dev", "dsp_synth_bursts_dev",
                  "dsp_sync_capture_segmented", "dsp_sync_capture_segmented_dev", "dsp_synth_stream_dev", "dsp_lagrange_resample", "dsp_fll_class", "dsp_diff_corr",
                  "dsp_cfo_preamble", "dsp_cfo_fourth_power", "dsp_derotate", "dsp_rx_bursts", "dsp_cfo_derotate_dev", "dsp_fll_slicer", "dsp_trim",
-                 "dsp_device_info", "dsp_capture_validate"):
+                 "dsp_device_info", "dsp_capture_validate", "dsp_fir_tiles_static_dev"):
         getattr(L, name).restype = ci
 
 

@@ -8,6 +8,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
 #include <vector>
 
 struct dsp_ctx {
@@ -27,6 +28,7 @@ struct dsp_ctx {
     int fir_stream;     // matched filter of <= 41 taps: 2 = persistent fir_strip_kernel where eligible (default),
                         // 1 = fir_stream_kernel, 0 = the tap-blocked kernel
     double *fir_taps;   // [64] the stream kernel's zero-padded taps
+    void *static_scratch;   // this device's address of the static `scratch` array
     int prio_period;    // split kernel: priority rotation period in DMA blocks (power of two), 0 = off
     // grow-only device scratch kept between calls of the segment-parallel mode (its window tiles are
     // gigabytes: hipMalloc / hipFree per call cost milliseconds); released by dsp_trim / dsp_destroy
@@ -37,6 +39,16 @@ struct dsp_ctx {
     int trace_stamps;
 #endif
 };
+
+// Scratch of dsp_fir_tiles_static_dev, the one entry point that allocates nothing: partial statistics
+// and padded taps of one matched-filter call.  Every GPU the library runs on holds its own copy of the
+// array (at its own address) until the process ends.  In host code `scratch` is only a handle for
+// hipGetSymbolAddress: dsp_create asks for the device address once per device and everything below
+// uses that pointer (ctx->static_scratch), never the name.
+#define DSP_STATIC_SCRATCH_BYTES (16u << 20)
+static __device__ __align__(256) unsigned char scratch[DSP_STATIC_SCRATCH_BYTES];
+static std::mutex g_scratch_mu;
+static void *g_scratch_addr[64];        // device address of `scratch` per device ordinal
 
 static thread_local char g_err[512] = "";
 
@@ -155,6 +167,17 @@ int dsp_create(int device_id, dsp_ctx **out)
     if (e == hipSuccess) e = hipMalloc((void **)&c->cu_tickets, 4096 * sizeof(unsigned));
     if (e == hipSuccess) e = hipMemset(c->cu_tickets, 0, 4096 * sizeof(unsigned));
     if (e == hipSuccess) e = hipMalloc((void **)&c->fir_taps, 64 * sizeof(double));
+    c->static_scratch = nullptr;
+    if (e == hipSuccess) {
+        // once per device, with that device current (hipSetDevice above)
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        if (device_id < 64 && !g_scratch_addr[device_id]) {
+            void *p = nullptr;
+            e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+            if (e == hipSuccess) g_scratch_addr[device_id] = p;
+        }
+        if (device_id < 64) c->static_scratch = g_scratch_addr[device_id];
+    }
     if (e != hipSuccess) {
         // release whatever was created before the step that failed
         if (c->fir_taps) (void)hipFree(c->fir_taps);
@@ -664,9 +687,11 @@ int64_t dsp_fir_workspace_bytes(int in_kind, int64_t B, int64_t N, int n_taps)
     return (int64_t)B * ((P.nchunk > Q.nchunk ? P.nchunk : Q.nchunk) + 8) * 4 * 8;     // + 8: fir_plan_strips
 }
 
-int dsp_fir_tiles_dev(dsp_ctx *c, const dsp_fir_args *a)
+// The matched filter on device bursts; `ws` / `ws_bytes` hold the partial statistics, `taps_buf` (>= 64
+// doubles) the stream kernels' zero-padded taps.  Launches only: no allocation, no synchronisation.
+static int fir_tiles_run(dsp_ctx *c, const dsp_fir_args *a, void *ws, int64_t ws_bytes, double *taps_buf,
+                         const char *ws_name)
 {
-    if (!c || !a) return fail(DSP_E_ARG, "ctx/args is NULL");
     if (a->B <= 0) return DSP_OK;
     if (!a->src || !a->h || a->n_taps < 1) return fail(DSP_E_ARG, "fir: NULL src/h or no taps");
     if (a->in_kind < 0 || a->in_kind > 2) return fail(DSP_E_ARG, "fir: bad in_kind");
@@ -676,20 +701,42 @@ int dsp_fir_tiles_dev(dsp_ctx *c, const dsp_fir_args *a)
     memset(&P, 0, sizeof(P));
     if (!fir_plan(a->in_kind, a->n_taps, (int)a->N, P, c->fir_stream != 0))
         return fail(DSP_E_ARG, "fir: %d taps are too many for the LDS-tiled kernel", a->n_taps);
-    P.h_pad = c->fir_taps; P.strip_ok = c->fir_stream == 2; P.n_cu = c->n_cu;
+    P.h_pad = taps_buf; P.strip_ok = c->fir_stream == 2; P.n_cu = c->n_cu;
     const bool want_std = a->std_out || a->inv_std_out;
-    if (want_std && (!a->workspace || a->workspace_bytes < (int64_t)a->B * (P.nchunk + 8) * 32))
-        return fail(DSP_E_ARG, "fir: workspace too small (need %lld bytes)", (long long)a->B * (P.nchunk + 8) * 32);
+    if (want_std && (!ws || ws_bytes < (int64_t)a->B * (P.nchunk + 8) * 32))
+        return fail(DSP_E_ARG, "fir: %s too small (need %lld bytes, have %lld)", ws_name,
+                    (long long)a->B * (P.nchunk + 8) * 32, (long long)ws_bytes);
     P.src = a->src; P.ld = a->src_stride; P.lens = a->lens; P.len_all = (int)a->N; P.B = (int)a->B;
     P.h = a->h; P.M = a->n_taps; P.start = a->start < 0 ? (a->n_taps - 1) / 2 : a->start;
     P.in_scale = a->in_scale; P.dst = a->tiles; P.rows = (int)a->rows; P.scale = a->scale;
-    P.stats = want_std ? (double *)a->workspace : nullptr;
+    P.stats = want_std ? (double *)ws : nullptr;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(launch_fir_tile(P, a->in_kind, c->stream));
     if (want_std)
         HIP_TRY(launch_fir_stats_finish(P, a->std_out, a->inv_std_out, c->stream));
     return DSP_OK;
 }
+
+int dsp_fir_tiles_dev(dsp_ctx *c, const dsp_fir_args *a)
+{
+    if (!c || !a) return fail(DSP_E_ARG, "ctx/args is NULL");
+    return fir_tiles_run(c, a, a->workspace, a->workspace_bytes, c->fir_taps, "workspace");
+}
+
+// dsp_fir_tiles_dev for callers that cannot allocate (and cannot hand over a workspace): the partial
+// statistics and the padded taps live in the library's static device array instead.  The first 512 bytes
+// hold the taps, the rest the statistics records; every record a call reads is written by that call
+// first, so nothing has to start at zero.  Calls that overlap on one GPU share the array and race.
+int dsp_fir_tiles_static_dev(dsp_ctx *c, const dsp_fir_args *a)
+{
+    if (!c || !a) return fail(DSP_E_ARG, "ctx/args is NULL");
+    if (!c->static_scratch) return fail(DSP_E_HIP, "fir: the static scratch array has no device address");
+    unsigned char *base = (unsigned char *)c->static_scratch;
+    return fir_tiles_run(c, a, base + 512, (int64_t)DSP_STATIC_SCRATCH_BYTES - 512, (double *)base,
+                         "static scratch (dsp_static_scratch_bytes())");
+}
+
+int64_t dsp_static_scratch_bytes(void) { return (int64_t)DSP_STATIC_SCRATCH_BYTES; }
 
 int dsp_load_iq_i16(dsp_ctx *c, const int16_t *iq, int64_t n_words, int normalize, float *out_c64,
                     int64_t *n_out)

@@ -202,6 +202,20 @@ int64_t dsp_fir_workspace_bytes(int in_kind, int64_t B, int64_t N, int n_taps);
  * Returns DSP_E_ARG if the filter is too long for the LDS-tiled kernel (n_taps > ~80). */
 int dsp_fir_tiles_dev(dsp_ctx *ctx, const dsp_fir_args *args);
 
+/* dsp_fir_tiles_dev without any allocation -- NO COUNTERPART IN THE REFERENCE.  For callers that cannot
+ * call hipMalloc or bring a workspace: code under HIP graph capture, tight serving loops, harnesses
+ * that forbid allocation.  Same arguments, same kernels and bit-identical results, but args->workspace
+ * / workspace_bytes are ignored: the partial statistics and the padded taps live in a static device
+ * array of dsp_static_scratch_bytes() = 16 MiB that every GPU the library runs on holds until the
+ * process ends.  A call that needs more -- 512 + B * (ceil(N / chunk) + 8) * 32 bytes when std_out /
+ * inv_std_out is wanted; B = 4096 bursts of 8192 samples need 10.7 MB -- returns DSP_E_ARG and launches
+ * nothing.  The call makes no hipMalloc / hipFree (nor does anything it calls) and does not
+ * synchronise.  All calls on one GPU share the array: calls that overlap in time there (two contexts,
+ * two streams) race; calls on one context's stream are ordered and safe.  Nothing needs clearing: a
+ * call writes every record it later reads.                                                        */
+int dsp_fir_tiles_static_dev(dsp_ctx *ctx, const dsp_fir_args *args);
+int64_t dsp_static_scratch_bytes(void);
+
 /* Differential-correlation preamble search -- the sliding loop of
  * find_preamble_offset, diff_method.py:118-148 (= worker.py:183-245): for phase in 0..sps-1,
  * s = x[phase::sps], d = s[1:]*conj(s[:-1]), conv[phase][k] = sum(d[k:k+L]*conj(d_pre)) /
