@@ -435,8 +435,7 @@ __global__ __launch_bounds__(64 * NW) void fir_stream_kernel(FirParams P)
 
 // ---------------------------------------------------------------------------
 // fir_strip_kernel: fir_stream_kernel made persistent along the burst.  One workgroup owns one FULL tile
-// (64 bursts of equal length) x one strip of consecutive INTERIOR chunks (chunks whose window lies wholly
-// inside the bursts) and walks them in order:
+// (64 bursts of equal length) x one strip of consecutive chunks and walks them in order:
 //   * every input sample is read from HBM ONCE: the FIR_MT - 1 samples two neighbouring chunks share
 //     stay in LDS (moved to the front of each row), only the chunk's CH new samples per burst are loaded
 //     (the chunk-per-workgroup kernels read W / CH = 1.36 x the input);
@@ -447,8 +446,10 @@ __global__ __launch_bounds__(64 * NW) void fir_stream_kernel(FirParams P)
 //     rate with two waves per SIMD; two 512-thread workgroups per CU = four);
 //   * the np.std statistics stay in the wave's registers for the whole strip: one (n, mean, M2) record
 //     per (burst, strip, wave) at the end -- no per-chunk LDS reduction, two barriers per chunk;
-//   * no bounds logic anywhere: the chunks at the two ends of the bursts and a partly filled last tile
-//     are left to fir_stream_kernel (launch_fir_stream_t runs it over just those).
+//   * the bursts' ends cost a zero-select where a strip's first window is loaded and a second, masked
+//     copy of the (short) epilogue and LDS write for the chunk that holds the end: all tests are
+//     wave-uniform because the bursts are equally long.  A partly filled last tile is left to
+//     fir_stream_kernel (launch_fir_stream_t runs it over just that tile).
 // Outputs and per-output sums are the same bits as fir_stream_kernel / fir_tile_kernel.
 template <typename IN> struct Wide;                                   // 16 bytes of input samples
 template <> struct Wide<f2v> { typedef float T __attribute__((ext_vector_type(4))); enum { SPL = 2 }; };
@@ -489,27 +490,34 @@ __global__ __launch_bounds__(512, 4) void fir_strip_kernel(FirParams P)
     const double scale = SCALED ? P.scale[b] : 1.0;
     double s_re = 0.0, s_im = 0.0, s_sq = 0.0, c_re = 0.0, c_im = 0.0;
 
-    // ---- the first chunk's whole window --------------------------------------------------
+    const int len = P.len_all, rows = P.rows;
+    int cnt = 0;                                        // outputs of this wave that count (wave-uniform)
+
+    // ---- the first chunk's whole window (16-byte pieces; a piece lies wholly inside or outside the burst:
+    //      launch_fir_tile checks that the burst's ends fall on piece boundaries) ----------------
     {
         WV v[RQ][NPL];
+        const int g0 = c_lo * CH + P.start - HALO;      // burst sample of the window's first sample
 #pragma unroll
         for (int q = 0; q < RQ; q++) {
-            const WV *src = (const WV *)(rows0 + (int64_t)q * P.ld + (int64_t)c_lo * CH);
+            const IN *src = rows0 + (int64_t)q * P.ld + HALO - P.start;        // the row's sample 0
 #pragma unroll
             for (int k = 0; k < NPL; k++) {
-                int i = lane + 64 * k;
-                i = i < WPR ? i : WPR - 1;
-                v[q][k] = __builtin_nontemporal_load(src + i);
+                int g = g0 + (lane + 64 * k) * SPL;
+                g = g < 0 ? 0 : (g > len - SPL ? len - SPL : g);
+                v[q][k] = __builtin_nontemporal_load((const WV *)(src + g));
             }
         }
 #pragma unroll
         for (int q = 0; q < RQ; q++) {
 #pragma unroll
             for (int k = 0; k < NPL; k++) {
-                const int i = lane + 64 * k;
+                const int i = lane + 64 * k, g = g0 + i * SPL;
+                const bool in = g >= 0 && g + SPL <= len;
                 if (i < WPR) {
 #pragma unroll
-                    for (int u = 0; u < SPL; u++) myrows[q * stride + i * SPL + u] = to_stage(wide_get(v[q][k], u), isc);
+                    for (int u = 0; u < SPL; u++)
+                        myrows[q * stride + i * SPL + u] = in ? to_stage(wide_get(v[q][k], u), isc) : ST{0, 0};
                 }
             }
         }
@@ -518,28 +526,50 @@ __global__ __launch_bounds__(512, 4) void fir_strip_kernel(FirParams P)
 
     for (int c = c_lo; c < c_hi; c++) {
         // chunk c + 1's new samples (the last chunk of the strip loads its own again and drops them:
-        // an unconditional load keeps the loop free of joins the compiler would wait at)
+        // an unconditional load keeps the loop free of joins the compiler would wait at); pieces past
+        // the burst's end re-read its last one and are zeroed when they go to LDS
         WV pre[RQ];
+        const int cn = c + 1 < c_hi ? c + 1 : c;
+        const int gn = cn * CH + P.start + (lane < LPR ? lane : LPR - 1) * SPL;     // first sample of this lane's piece
         {
-            const int cn = c + 1 < c_hi ? c + 1 : c;
-            const int ln = lane < LPR ? lane : LPR - 1;
+            const int g = gn > len - SPL ? len - SPL : gn;
 #pragma unroll
             for (int q = 0; q < RQ; q++) {
-                const WV *src = (const WV *)(rows0 + (int64_t)q * P.ld + (int64_t)cn * CH + HALO);
-                pre[q] = __builtin_nontemporal_load(src + ln);
+                const IN *src = rows0 + (int64_t)q * P.ld + HALO - P.start;
+                pre[q] = __builtin_nontemporal_load((const WV *)(src + g));
             }
         }
         double are[OG], aim[OG];
         stream_block<ST, OG>(xs, lane * stride + w * OG, hp, are, aim);
-        // every output is valid, counted and stored once
         if (c == c_lo) { c_re = are[0]; c_im = aim[0]; }
-        OUT *drow = dst + (size_t)(c * CH + w * OG) * 64;
+        const int n_a = c * CH + w * OG;
+        OUT *drow = dst + (size_t)n_a * 64;
+        if (c * CH + CH <= len && c * CH + CH <= rows) {
+            // every output is valid, counted and stored once
 #pragma unroll
-        for (int o = 0; o < OG; o++) {
-            const double dr = are[o] - c_re, di = aim[o] - c_im;
-            s_re += dr; s_im += di;
-            s_sq = __builtin_fma(di, di, __builtin_fma(dr, dr, s_sq));        // statistics only: free to fuse
-            if (STORE) put(drow + (size_t)o * 64, SCALED ? are[o] * scale : are[o], SCALED ? aim[o] * scale : aim[o]);
+            for (int o = 0; o < OG; o++) {
+                const double dr = are[o] - c_re, di = aim[o] - c_im;
+                s_re += dr; s_im += di;
+                s_sq = __builtin_fma(di, di, __builtin_fma(dr, dr, s_sq));        // statistics only: free to fuse
+                if (STORE) put(drow + (size_t)o * 64, SCALED ? are[o] * scale : are[o], SCALED ? aim[o] * scale : aim[o]);
+            }
+            cnt += OG;
+        } else {
+            // the chunk that holds the burst's end: outputs past it are zeros and do not count (the
+            // bursts are equally long, so every test is wave-uniform)
+#pragma unroll
+            for (int o = 0; o < OG; o++) {
+                const bool valid = n_a + o < len;
+                if (valid) {
+                    const double dr = are[o] - c_re, di = aim[o] - c_im;
+                    s_re += dr; s_im += di;
+                    s_sq = __builtin_fma(di, di, __builtin_fma(dr, dr, s_sq));
+                    cnt++;
+                }
+                if (STORE && n_a + o < rows)
+                    put(drow + (size_t)o * 64, valid ? (SCALED ? are[o] * scale : are[o]) : 0.0,
+                        valid ? (SCALED ? aim[o] * scale : aim[o]) : 0.0);
+            }
         }
         if (c + 1 == c_hi) break;
         // the window of chunk c + 1 = the last HALO samples of this window + the CH prefetched ones.  Every
@@ -558,11 +588,21 @@ __global__ __launch_bounds__(512, 4) void fir_strip_kernel(FirParams P)
                 if (idx < RQ * HALO) myrows[q * stride + i] = keep[j];
             }
             if (lane < LPR) {
+                if (cn * CH + P.start + CH <= len) {
 #pragma unroll
-                for (int q = 0; q < RQ; q++) {
+                    for (int q = 0; q < RQ; q++) {
 #pragma unroll
-                    for (int u = 0; u < SPL; u++)
-                        myrows[q * stride + HALO + lane * SPL + u] = to_stage(wide_get(pre[q], u), isc);
+                        for (int u = 0; u < SPL; u++)
+                            myrows[q * stride + HALO + lane * SPL + u] = to_stage(wide_get(pre[q], u), isc);
+                    }
+                } else {
+                    const bool in = gn + SPL <= len;
+#pragma unroll
+                    for (int q = 0; q < RQ; q++) {
+#pragma unroll
+                        for (int u = 0; u < SPL; u++)
+                            myrows[q * stride + HALO + lane * SPL + u] = in ? to_stage(wide_get(pre[q], u), isc) : ST{0, 0};
+                    }
                 }
             }
         }
@@ -570,9 +610,9 @@ __global__ __launch_bounds__(512, 4) void fir_strip_kernel(FirParams P)
     }
     if (P.stats) {
         // this lane's (n, mean, M2) over the strip as record strip * NW + w of its burst
-        const double n = (double)((c_hi - c_lo) * OG);
-        const double mr = s_re / n, mi = s_im / n;                             // mean of (y - c)
-        double m2 = s_sq - n * (mr * mr + mi * mi);
+        const double n = (double)cnt;
+        const double mr = cnt ? s_re / n : 0.0, mi = cnt ? s_im / n : 0.0;    // mean of (y - c)
+        double m2 = cnt ? s_sq - n * (mr * mr + mi * mi) : 0.0;
         if (m2 < 0.0) m2 = 0.0;
         double *st = P.stats + ((size_t)b * P.nrec + strip * NW + w) * 4;
         st[0] = n; st[1] = c_re + mr; st[2] = c_im + mi; st[3] = m2;
@@ -913,13 +953,8 @@ static void fir_plan_strips(FirParams &P, int in_kind)
     const int spl = in_kind == DSP_IN_I16 ? 4 : 2;                     // samples per 16 bytes
     const int esz = in_kind == DSP_IN_I16 ? 4 : 8;
     if (P.ld % spl || (P.start - (FIR_MT - 1)) % spl || ((uintptr_t)P.src & 15) || (P.ld * esz) % 16) return;
-    const int halo = FIR_MT - 1;
-    // interior: window [c*CH + start - halo, c*CH + start + CH) inside [0, len), all CH outputs inside the rows
-    int c0 = 0;
-    while (c0 * P.CH + P.start - halo < 0) c0++;
-    int c1 = (P.len_all - P.start) / P.CH;
-    if (c1 > P.nchunk) c1 = P.nchunk;
-    while (c1 > 0 && (c1 * P.CH > P.rows || c1 * P.CH > P.len_all)) c1--;
+    if (P.len_all % spl || P.rows < P.len_all || P.start < 0) return;   // the bursts' ends fall on 16-byte pieces
+    const int c0 = 0, c1 = P.nchunk;                                     // the strips cover every chunk
     const int nint = c1 - c0, full = P.B / 64;
     if (nint < 8 || full < 1) return;
     const int n_cu = P.n_cu > 0 ? P.n_cu : 256;
