@@ -175,6 +175,9 @@ def parse_args(argv=None):
     ap.add_argument("--lean", action="store_true",
                     help="also time the launch with decisions as the only output (informational; off by "
                          "default so that every launch of a profiled run is the measured one)")
+    ap.add_argument("--interp-half-len", type=int, default=0,
+                    help="(2h+1)-point Lagrange interpolator inside the timing loop instead of the reference's "
+                         "linear one (informational runs; 0 = the metric's configuration)")
     ap.add_argument("--ring-rows", type=int, default=0)
     ap.add_argument("--lds-pad", type=int, default=-1)
     ap.add_argument("--split", type=int, default=-1, help="-1 auto, 0 one wave per tile, 1 two")
@@ -229,7 +232,7 @@ def rank_main(args):
     B_res = max(B, B_other)
 
     # ---- synthetic bursts generated on the device, matched-filtered, resident in HBM ----
-    pipe = BurstPipeline(ctx, B_res, N_SYM, SPS, alpha=ALPHA, Bn=BN, y=Y)
+    pipe = BurstPipeline(ctx, B_res, N_SYM, SPS, alpha=ALPHA, Bn=BN, y=Y, interp_half_len=args.interp_half_len)
     pipe.generate(SEED, b0=b_lo)
     pipe.matched_filter()                      # warm-up pass (first launch of the kernel)
     ctx.synchronize()
@@ -328,7 +331,7 @@ def rank_main(args):
                        "Gardner(alpha .007)+FLL(Bn .03)+decisions, all 7 outputs",
            "bursts_per_gpu": B, "bursts_total": total, "samples_per_burst": N,
            "generator": "on-device, counter-based RNG", "min_symbol_match_rate": worst,
-           "matched_filter_ms": fir_ms,
+           "matched_filter_ms": fir_ms, "interp_half_len": args.interp_half_len,
            "parallelism": f"bursts sharded x{world}, no collective",
            args.scaling + "_scaling": mode_cfg}
     if other_rec:

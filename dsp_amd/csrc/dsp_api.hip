@@ -469,7 +469,11 @@ int dsp_sync_tiles_dev(dsp_ctx *c, const dsp_sync_args *a)
     // many tiles a CU holds (160 KiB per CU), so size it for an even spread over 256 CUs.
     const int elem = a->dtype == DSP_C128 ? 16 : 8;
     const int ntiles = (P.B + 63) / 64;
-    const bool can_split = fll && a->variant != 2 && P.half_len == 0;
+    // two waves per tile: both loops run, and the interpolator is the reference's linear one or the
+    // Lagrange one the two-wave kernel is built for (gardner2 variant, half_len 1, 2, 4)
+    const bool can_split = fll && a->variant != 2 &&
+                           (P.half_len == 0 || (a->variant == DSP_GARDNER2 &&
+                                                (P.half_len == 1 || P.half_len == 2 || P.half_len == 4)));
     const int n_store_t = count_nonnull({P.rec, P.terr, P.mu, P.pos});
     const int n_store_f = count_nonnull({P.sig, P.freq, P.ef, P.dec});
     int per_cu = (ntiles + c->n_cu - 1) / c->n_cu;

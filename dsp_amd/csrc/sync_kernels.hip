@@ -25,6 +25,14 @@
 #include "dsp_internal.h"
 #include "sync_lane.h"
 
+// This file is compiled twice (Makefile): part 0 holds every kernel with the reference's linear
+// interpolator, the one-wave kernels and the launch logic; part 1 (-DDSP_SYNC_PART=1) only the
+// two-wave kernel with the Lagrange interpolator inside the timing loop (half_len 1, 2, 4), so that
+// the two sets of instantiations build side by side.
+#ifndef DSP_SYNC_PART
+#define DSP_SYNC_PART 0
+#endif
+
 #pragma clang fp contract(off)
 
 using dspm::cd;
@@ -367,6 +375,98 @@ __device__ __forceinline__ bool g2_steady(const Tile<IN> &tl, dspm::GState &gs, 
     return true;
 }
 
+// ---------------------------------------------------------------------------
+// The timing loop with a (2H+1)-point Lagrange interpolator (hw1/test_lagrange_resampling.py:34-72) in
+// place of interpolate(): steady-state iteration, straight-line code out of the LDS ring.
+//   * basis values in product form, L_i(f) = w_i * prod_{j != i} (f - o_j), o = -H..H, from prefix and
+//     suffix products: no division and no exact-node case (the barycentric form of lagrange_at divides
+//     twice per tap and once per output; both evaluate the same polynomial, they agree to ~1e-15);
+//   * early, mid and late instants differ by whole samples, so they share ONE set of basis values
+//     (when their fractions are not bit-identical -- a power of two between them -- the iteration is
+//     left to the per-lane code); the output instant k + mu_new needs a second set and, as long as it
+//     falls between the same two samples as the late one, no further samples.
+// Returns false (state untouched) when a lane fails the vote.
+template <int H>
+__device__ __forceinline__ void lagr_basis(double f, double (&L)[2 * H + 1])
+{
+    constexpr int T = 2 * H + 1;
+    dspm::LagrangeW W;
+    dspm::lagrange_weights(H, W);                       // compile-time constants
+    double d[T], pre[T], suf[T];
+#pragma unroll
+    for (int i = 0; i < T; i++) d[i] = f - (double)(i - H);
+    pre[0] = 1.0;
+#pragma unroll
+    for (int i = 1; i < T; i++) pre[i] = pre[i - 1] * d[i - 1];
+    suf[T - 1] = 1.0;
+#pragma unroll
+    for (int i = T - 2; i >= 0; i--) suf[i] = suf[i + 1] * d[i + 1];
+#pragma unroll
+    for (int i = 0; i < T; i++) L[i] = W.w[i] * (pre[i] * suf[i]);
+}
+
+template <int H>
+__device__ __forceinline__ cd lagr_dot(const double (&L)[2 * H + 1], const cd (&x)[2 * H + 1])
+{
+    cd z; z.re = 0.0; z.im = 0.0;
+#pragma unroll
+    for (int i = 0; i < 2 * H + 1; i++) {
+        z.re = __builtin_fma(L[i], x[i].re, z.re);
+        z.im = __builtin_fma(L[i], x[i].im, z.im);
+    }
+    return z;
+}
+
+template <typename IN, bool SC, int H>
+__device__ __forceinline__ bool g2_steady_lagr(const Tile<IN> &tl, dspm::GState &gs, const TimingConst &tc,
+                                               const dspm::LagrangeW *Lp, cd &rec, double &err, double &pos)
+{
+    constexpr int T = 2 * H + 1;
+    const double mu = gs.mu, spsd = tc.spsd;
+    const double kd = (double)gs.k;
+    const double i_a = (kd - spsd) + mu;                 // gardner2.py:76-78
+    const double i_b = (kd - tc.halfd) + mu;
+    const double i_c = kd + mu;
+    const int r_a = __double2int_rz(i_a), r_b = __double2int_rz(i_b), r_c = __double2int_rz(i_c);
+    const double f = dspm::fract_pos(i_a);
+    const bool in = (mu < spsd) & (mu >= -spsd) & (r_a - H >= tl.win_lo) & (r_c + 1 + H < tl.win_hi) &
+                    (int)(dspm::fract_pos(i_b) == f) & (int)(dspm::fract_pos(i_c) == f);
+    if (!__all(in)) return false;
+    double L[T];
+    lagr_basis<H>(f, L);
+    cd xa[T], xb[T], xc[T];
+#pragma unroll
+    for (int i = 0; i < T; i++) {
+        xa[i] = tl.template lds_at<SC>(r_a - H + i);
+        xb[i] = tl.template lds_at<SC>(r_b - H + i);
+        xc[i] = tl.template lds_at<SC>(r_c - H + i);
+    }
+    const cd va = lagr_dot<H>(L, xa), vb = lagr_dot<H>(L, xb), vc = lagr_dot<H>(L, xc);
+    const double e = dspm::ted_error(va, vb, vc);        // :87
+    const double mu_n = mu - tc.alpha * e;               // :91
+    const double i_o = kd + mu_n;                        // :95
+    const int r_o = __double2int_rz(i_o);
+    if (__all(r_o == r_c)) {                             // the late instant's samples serve
+        double Lo[T];
+        lagr_basis<H>(dspm::fract_pos(i_o), Lo);
+        rec = lagr_dot<H>(Lo, xc);
+    } else if (__all((i_o > 0.0) & (i_o < 1.0e9) & (r_o - H >= tl.win_lo) & (r_o + 1 + H < tl.win_hi))) {
+        double Lo[T];
+        lagr_basis<H>(dspm::fract_pos(i_o), Lo);
+        cd xo[T];
+#pragma unroll
+        for (int i = 0; i < T; i++) xo[i] = tl.template lds_at<SC>(r_o - H + i);
+        rec = lagr_dot<H>(Lo, xo);
+    } else {
+        rec = dspm::g2_interp(i_o, tc.len, Lp, FetchFn<IN>{tl});
+    }
+    err = e;
+    pos = i_o;
+    gs.mu = mu_n;
+    gs.k += tc.sps;                                      // :98
+    return true;
+}
+
 // sample position of the symbol an iteration just produced: k + mu with the updated mu
 // (gardner2.py:95) / idx_k (hw1/gardner.py:47); the k in gs has already advanced
 template <int VARIANT>
@@ -566,7 +666,7 @@ __device__ __forceinline__ unsigned wave_slot()
 //   fills the other half.  Every block both waves execute exactly one barrier.
 // NWV = waves launched per tile: 2, or 3 / 4 with idle waves for the dispatcher (below); separate
 // instantiations so that the plain launch compiles exactly as it did without them (0.9 % at B = 65 536)
-template <typename IN, int VARIANT, bool SC, int NWV>
+template <typename IN, int VARIANT, bool SC, int NWV, int H = 0>
 __global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
 {
     typedef typename InT<IN>::OS OS;
@@ -652,6 +752,9 @@ __global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
         TimingConst tc;
         dspm::GState gs;
         timing_init(tc, gs, P, VARIANT, len, lane_ok, b);
+        dspm::LagrangeW LW;                             // H > 0: the per-lane code's barycentric weights
+        const dspm::LagrangeW *Lp = nullptr;
+        if (H > 0) { dspm::lagrange_weights(H, LW); Lp = &LW; }
         OC *o_rec = (OC *)P.rec; OS *o_terr = (OS *)P.terr; OS *o_mu = (OS *)P.mu; OS *o_pos = (OS *)P.pos;
         int n_rec = 0;
         if (VARIANT == DSP_VARIANT_GARDNER2) {
@@ -691,7 +794,8 @@ __global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
                 bool done = false;
                 if (steady) {
                     cd rec; double e, ps;
-                    done = g2_steady<IN, SC>(tl, gs, tc, rec, e, ps);
+                    if constexpr (H > 0) done = g2_steady_lagr<IN, SC, H>(tl, gs, tc, Lp, rec, e, ps);
+                    else done = g2_steady<IN, SC>(tl, gs, tc, rec, e, ps);
                     if (done) {
                         DSP_TR(trp, 5);
                         const unsigned row_s = (unsigned)it * 64u * (unsigned)sizeof(OS);
@@ -711,7 +815,7 @@ __global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
                 if (!done) {
                     const int rec_row = it + ROFF;
                     if (gs.active && rec_row >= cap_rows) { gs.active = false; overflow = true; }
-                    dspm::GOut go = timing_iter<IN, VARIANT, false, SC>(tl, gs, tc, nullptr, trp);
+                    dspm::GOut go = timing_iter<IN, VARIANT, (H > 0), SC>(tl, gs, tc, Lp, trp);
                     DSP_TR(trp, 5);
                     const int rrow = rec_row < cap_rows ? rec_row : cap_rows;
                     const int erow = it < cap_rows ? it : cap_rows;
@@ -810,7 +914,43 @@ __global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
 #endif
 }
 
+#if DSP_SYNC_PART == 1
+// the two-wave kernel with the Lagrange interpolator: half_len 1, 2 or 4, gardner2 variant, launched
+// with two waves per tile or with four (two of them chosen by the CU ticket, see above)
+template <typename IN>
+static hipError_t launch_split_lagr_t(const SyncParams &P, size_t lds, hipStream_t s)
+{
+    const int ntiles = (P.B + 63) / 64;
+    const bool four = P.spare_wave == 2 && P.cu_tickets;
+    void (*k)(SyncParams) = nullptr;
+#define DSP_LAGR_PICK(HH)                                                                      \
+    k = four ? sync_split_kernel<IN, DSP_VARIANT_GARDNER2, true, 4, HH>                         \
+             : sync_split_kernel<IN, DSP_VARIANT_GARDNER2, true, 2, HH>
+    switch (P.half_len) {
+        case 1: DSP_LAGR_PICK(1); break;
+        case 2: DSP_LAGR_PICK(2); break;
+        case 4: DSP_LAGR_PICK(4); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef DSP_LAGR_PICK
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, dim3(ntiles), dim3(four ? 256 : 128), lds, s, P);
+    return hipGetLastError();
+}
+#endif
+
 }  // namespace
+
+#if DSP_SYNC_PART == 1
+hipError_t launch_sync_split_lagr(const SyncParams &P, bool c128, size_t lds, hipStream_t s)
+{
+    return c128 ? launch_split_lagr_t<d2v>(P, lds, s) : launch_split_lagr_t<f2v>(P, lds, s);
+}
+#else
+hipError_t launch_sync_split_lagr(const SyncParams &P, bool c128, size_t lds, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // Ring schedule.  Iteration `it` of the timing loop touches rows
@@ -857,6 +997,8 @@ static hipError_t launch_v(const SyncParams &P, size_t lds, hipStream_t s)
 template <typename IN>
 static hipError_t launch_in(const SyncParams &P, int variant, bool fll, size_t lds, hipStream_t s)
 {
+    if (P.TQ > 0 && P.half_len > 0)   // ... with the Lagrange interpolator: the other translation unit
+        return launch_sync_split_lagr(P, sizeof(IN) == 16, lds, s);
     if (P.TQ > 0) {        // two waves per tile (timing wave + FLL wave)
         int ntiles = (P.B + 63) / 64;
         const int nwv = P.spare_wave == 2 && P.cu_tickets ? 4 : P.spare_wave ? 3 : 2;
@@ -894,3 +1036,4 @@ hipError_t launch_sync(const SyncParams &P, bool c128, int variant, bool fll, si
     return c128 ? launch_in<d2v>(P, variant, fll, lds_bytes, stream)
                 : launch_in<f2v>(P, variant, fll, lds_bytes, stream);
 }
+#endif  // DSP_SYNC_PART

@@ -27,7 +27,7 @@ class BurstPipeline:
     """B bursts of n_sym*sps complex64 samples on one GPU."""
 
     def __init__(self, ctx, B, n_sym=2048, sps=4, span=10, rolloff=0.35, alpha=0.007, mu0=0.0,
-                 Bn=0.03, y=1.0, outputs="all", variant=0):
+                 Bn=0.03, y=1.0, outputs="all", variant=0, interp_half_len=0):
         self.ctx, self.L = ctx, _lib.lib()
         self.B, self.n_sym, self.sps = int(B), int(n_sym), int(sps)
         self.N = self.n_sym * self.sps
@@ -51,7 +51,7 @@ class BurstPipeline:
         self.d_ws, self.ws_bytes = self._alloc(max(ws, 16)), ws
         a = SyncArgs()
         a.x = self.d_tiles; a.dtype = 0; a.variant = variant; a.B = self.B; a.N = self.N
-        a.in_rows = self.rows; a.sps = self.sps; a.interp_half_len = 0
+        a.in_rows = self.rows; a.sps = self.sps; a.interp_half_len = int(interp_half_len)
         a.alpha = alpha; a.mu0 = mu0; a.do_fll = 1; a.Bn = Bn; a.y = y
         for k in self.names:
             setattr(a, k, self.d_out[k])

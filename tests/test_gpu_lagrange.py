@@ -92,3 +92,44 @@ def test_gardner_with_lagrange_interpolator(oracle, ctx):
     na = int(a["n_out"][0])
     assert na == int(b["n_out"][0])
     assert np.mean(a["dec"][0, 50:na] == b["dec"][0, 50:na]) > 0.99
+
+
+def test_lagrange_two_wave_kernel_full_tiles_ragged(oracle, ctx):
+    """interp_half_len 1, 2, 4 through the fused chain (both loops -> the two-wave kernel, whose timing
+    wave interpolates out of the LDS ring with product-form Lagrange basis values): full tiles of
+    bursts with ragged lengths, every burst against the restated loop to 1e-12 -- the per-lane code
+    (barycentric form) serves burst starts, ends and idle lanes, the straight-line code the rest --
+    and the one-wave kernel (split = 0) within 1e-12 of it too."""
+    import dsp_amd
+    g = golden("g_synth_bursts")
+    h = oracle.rrc_filter(4, 10, 0.35)
+    Y = np.stack([oracle.filter_samples(g["x"][b % 32], h) for b in range(70)])
+    Y = np.roll(Y, 3, axis=1) * (1.0 + 0.01 * np.arange(70))[:, None]       # 70 distinct bursts
+    N = 2400
+    Y = Y[:, :N]
+    rng = np.random.default_rng(41)
+    lens = rng.integers(1200, N + 1, 70).astype(np.int32)
+    lens[:4] = [N, N - 1, 1200, 1777]
+    for half in (1, 2, 4):
+        r = dsp_amd.sync_chain_batch(Y, 4, 0.007, 0.0, 0.03, 1, interp_half_len=half, lens=lens,
+                                     outputs=("rec", "err", "mu", "dec", "freq"), ctx=ctx)
+        ctx.set_option("split", 0)
+        try:
+            r1 = dsp_amd.sync_chain_batch(Y, 4, 0.007, 0.0, 0.03, 1, interp_half_len=half, lens=lens,
+                                          outputs=("rec", "err", "mu", "dec", "freq"), ctx=ctx)
+        finally:
+            ctx.set_option("split", -1)
+        assert np.array_equal(r["n_out"], r1["n_out"])
+        for b in list(range(0, 70, 9)) + [1, 2, 3, 63, 64, 69]:
+            L = int(lens[b])
+            rec, err, mu = gardner2_lagrange_restated(oracle, Y[b, :L], 4, 0.007, half)
+            n = int(r["n_out"][b])
+            assert n == len(rec), (half, b)
+            assert np.max(np.abs(r["mu"][b, :n - 1] - mu)) < 1e-12, (half, b)
+            assert np.max(np.abs(r["err"][b, :n - 1] - err)) < 1e-12, (half, b)
+            assert np.max(np.abs(r["rec"][b, :n] - rec)) < 1e-12, (half, b)
+            assert np.max(np.abs(r1["mu"][b, :n - 1] - mu)) < 1e-12, (half, b)
+            out = oracle.fll_func(rec, 0.03, 1)
+            assert np.array_equal(r["dec"][b, :n], oracle.quadrants(out[0])), (half, b)
+            assert np.max(np.abs(r["freq"][b, :n] - out[2])) < 1e-12
+            assert not r["rec"][b, n:].any()
