@@ -1416,22 +1416,43 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
         // into the np.std of the whole filtered stream; 1/std is applied by the recurrence kernel
         FirParams Q;
         memset(&Q, 0, sizeof(Q));
-        if (!fir_plan(a->in_kind, a->n_taps, (int)Nw, Q, c->fir_stream != 0))
-            return fail(DSP_E_ARG, "capture: %d taps are too many for the LDS-tiled filter", a->n_taps);
-        Q.h_pad = c->fir_taps;
-        HIP_TRY(ctx_scratch(c, 6, (size_t)S * Q.nchunk * 32, &d_ws.p));
-        Q.src = a->x; Q.starts = d_starts.as<int64_t>(); Q.n_total = n; Q.lens = d_lens.as<int>();
-        Q.stat_lo = d_lo.as<int>(); Q.stat_hi = d_hi.as<int>();
-        Q.len_all = (int)Nw; Q.B = S; Q.h = a->h; Q.M = a->n_taps; Q.start = (a->n_taps - 1) / 2;
-        Q.in_scale = in_scale; Q.dst = d_tiles.p; Q.rows = (int)rows; Q.stats = d_ws.as<double>();
-        // the warm-up rows of a window are rows its predecessor filters anyway: skip them here (every
-        // tile but the first) and copy them over afterwards
-        const bool share_lead = lead > 0 && lead <= seg && S > 64 && c->lead_copy != 2;
-        Q.skip_rows = share_lead ? (int)lead : 0;
-        Q.feed_lead = share_lead && c->lead_copy == 0 ? 1 : 0;     // the predecessor's workgroup stores them ...
-        HIP_TRY(launch_fir_tile(Q, a->in_kind, st));
-        if (share_lead && c->lead_copy == 1)                      // ... or a copy kernel does afterwards
-            HIP_TRY(launch_seg_lead_copy(d_tiles.p, (int)rows, d_starts.as<int64_t>(), S, (int)lead, st));
+        // (a) the stream cut into its segments, each filtered once by the persistent strip kernel, every
+        //     output stored into its own window and into the neighbours' warm-up / tail rows ...
+        bool by_segment = false;
+        if (c->fir_stream == 2 && c->lead_copy == 0 && S % 64 == 0 && n == (int64_t)S * seg && lead <= seg &&
+            tail <= seg && fir_plan(a->in_kind, a->n_taps, (int)seg, Q, true) && Q.stream) {
+            Q.stream_mode = 1; Q.strip_ok = 1; Q.n_cu = c->n_cu;
+            Q.lead_rows = (int)lead; Q.tail_rows = (int)tail;
+            Q.src = a->x; Q.n_total = n; Q.ld = seg; Q.len_all = (int)seg; Q.B = S;
+            Q.h = a->h; Q.M = a->n_taps; Q.start = (a->n_taps - 1) / 2; Q.h_pad = c->fir_taps;
+            Q.in_scale = in_scale; Q.dst = d_tiles.p; Q.rows = (int)rows;
+            by_segment = fir_stream_mode_plan(Q, a->in_kind);
+        }
+        if (by_segment) {
+            HIP_TRY(ctx_scratch(c, 6, (size_t)S * (Q.nchunk + 8) * 32, &d_ws.p));
+            Q.stats = d_ws.as<double>();
+            HIP_TRY(launch_fir_tile(Q, a->in_kind, st));
+            HIP_TRY(launch_seg_zero_past(d_tiles.p, (int)rows, d_lens.as<int>(), S, st));
+        } else {
+            // (b) ... or the overlapping windows themselves, chunk by chunk
+            memset(&Q, 0, sizeof(Q));
+            if (!fir_plan(a->in_kind, a->n_taps, (int)Nw, Q, c->fir_stream != 0))
+                return fail(DSP_E_ARG, "capture: %d taps are too many for the LDS-tiled filter", a->n_taps);
+            Q.h_pad = c->fir_taps;
+            HIP_TRY(ctx_scratch(c, 6, (size_t)S * Q.nchunk * 32, &d_ws.p));
+            Q.src = a->x; Q.starts = d_starts.as<int64_t>(); Q.n_total = n; Q.lens = d_lens.as<int>();
+            Q.stat_lo = d_lo.as<int>(); Q.stat_hi = d_hi.as<int>();
+            Q.len_all = (int)Nw; Q.B = S; Q.h = a->h; Q.M = a->n_taps; Q.start = (a->n_taps - 1) / 2;
+            Q.in_scale = in_scale; Q.dst = d_tiles.p; Q.rows = (int)rows; Q.stats = d_ws.as<double>();
+            // the warm-up rows of a window are rows its predecessor filters anyway: skip them here (every
+            // tile but the first) and copy them over afterwards
+            const bool share_lead = lead > 0 && lead <= seg && S > 64 && c->lead_copy != 2;
+            Q.skip_rows = share_lead ? (int)lead : 0;
+            Q.feed_lead = share_lead && c->lead_copy == 0 ? 1 : 0;     // the predecessor's workgroup stores them ...
+            HIP_TRY(launch_fir_tile(Q, a->in_kind, st));
+            if (share_lead && c->lead_copy == 1)                      // ... or a copy kernel does afterwards
+                HIP_TRY(launch_seg_lead_copy(d_tiles.p, (int)rows, d_starts.as<int64_t>(), S, (int)lead, st));
+        }
         HIP_TRY(launch_fir_stats_global(Q.stats, (int64_t)S * Q.nrec, S, nullptr, d_inv.as<double>(),
                                         d_part.as<double>(), 1024, st));
         d_scale = d_inv.as<double>();

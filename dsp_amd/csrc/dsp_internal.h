@@ -93,6 +93,9 @@ struct FirParams {
     int waves;                // waves per workgroup: 0 = auto (8 where the chunk divides), 4 = always 4
     int stream;               // set by fir_plan: 1 = fir_stream_kernel (<= 41 taps, float32 staging)
     int strip_ok;             // in: launch_fir_tile may use the persistent fir_strip_kernel
+    int stream_mode;          // in: the bursts are the consecutive segments of one stream of n_total samples
+                              //     (fir_strip_kernel STREAM; cleared by launch_fir_tile if it cannot serve)
+    int lead_rows, tail_rows; // in (stream_mode): warm-up rows / tail rows of a window in the tiles
     int n_cu;                 // in: compute units of the device (strip planning)
     // set by launch_fir_tile:
     int cps;                  // chunks per strip of fir_strip_kernel, 0 = chunk-per-workgroup kernels only
@@ -108,6 +111,9 @@ struct FirParams {
 
 bool fir_plan(int in_kind, int M, int n_out, FirParams &P, bool allow_stream = true);
 hipError_t launch_fir_tile(FirParams &P, int in_kind, hipStream_t s);
+// stream_mode requested: can fir_strip_kernel serve these parameters?  (false: clears stream_mode; the
+// caller falls back to the overlapping-window pass)
+bool fir_stream_mode_plan(FirParams &P, int in_kind);
 hipError_t launch_fir_stats_finish(const FirParams &P, double *std_out, double *inv_out, hipStream_t s);
 hipError_t launch_fir_stats_global(const double *stats, int64_t count, int B, double *std_out, double *inv_fill,
                                    double *partial, int n_partial, hipStream_t s);
@@ -147,6 +153,8 @@ struct SegParams {
 hipError_t launch_seg_windows(int S, int64_t n_total, int64_t seg_len, int64_t lead, int64_t tail,
                               int64_t *starts, int *lens, int *own_lo, int *own_hi, hipStream_t s);
 hipError_t launch_seg_lead_copy(void *tiles, int rows, const int64_t *starts, int S, int lead, hipStream_t s);
+// zero rows [lens[w], rows) of every window's lane (the rows the stream-mode filter pass does not write)
+hipError_t launch_seg_zero_past(void *tiles, int rows, const int *lens, int S, hipStream_t s);
 hipError_t launch_seg_phase(const void *tiles, int rows, const int *lens, int S, int sps, int n_sym, double *mu0,
                             hipStream_t s);
 hipError_t launch_seg_stitch(const SegParams &P, int overlap_vote, hipStream_t s);

@@ -457,8 +457,31 @@ template <> struct Wide<s2v> { typedef short T __attribute__((ext_vector_type(8)
 __device__ __forceinline__ f2v wide_get(const Wide<f2v>::T &v, int i) { return i ? f2v{v.z, v.w} : f2v{v.x, v.y}; }
 __device__ __forceinline__ s2v wide_get(const Wide<s2v>::T &v, int i) { return s2v{v[2 * i], v[2 * i + 1]}; }
 
-template <typename IN, typename OUT, int OG, bool SCALED, bool STORE>
-__global__ __launch_bounds__(512, 4) void fir_strip_kernel(FirParams P)
+// fir_strip_kernel STREAM: where lane `lane` of tile `tile` (window b) also stores its outputs -- its
+// successor's warm-up rows and its predecessor's tail rows, as pointers that take the output index n
+// directly.  Worked out inside the chunks that need them (the lane index goes through an empty asm so the
+// compiler cannot hoist the arithmetic out of the chunk loop and hold four more registers across it).
+template <typename OUT>
+__device__ __forceinline__ void neighbour_rows(const FirParams &P, int lane, int tile, OUT *&nxt, OUT *&prv, bool &has_nxt,
+                                               bool &has_prv)
+{
+    asm volatile("" : "+v"(lane));
+    const int b = tile * 64 + lane, lead = P.lead_rows;
+    has_nxt = b + 1 < P.B && lead > 0;
+    has_prv = b > 0 && P.tail_rows > 0;
+    // successor's row n - (len - lead); predecessor's row (start of its own rows) + len + n
+    nxt = (OUT *)P.dst + (size_t)((b + 1) >> 6) * P.rows * 64 + ((b + 1) & 63) - (ptrdiff_t)(P.len_all - lead) * 64;
+    prv = (OUT *)P.dst + (size_t)((b - 1) >> 6) * P.rows * 64 + ((b - 1) & 63) + (ptrdiff_t)((b - 1 > 0 ? lead : 0) + P.len_all) * 64;
+}
+
+// STREAM: the "bursts" are the consecutive segments of ONE long stream (segment-parallel capture mode;
+// burst b = stream samples [b * ld, (b + 1) * ld), len_all == ld).  A window then sees its true
+// neighbours across the segment edges and zeros only beyond the stream's two ends, and every output
+// goes to up to three places in the window tiles the recurrence kernel reads: the segment's own
+// window (rows own_row0 + n), the successor's warm-up rows (the last `lead_rows` outputs) and the
+// predecessor's tail rows (the first `tail_rows` outputs).
+template <typename IN, typename OUT, int OG, bool SCALED, bool STORE, bool STREAM = false>
+__global__ __launch_bounds__(512, STREAM ? 2 : 4) void fir_strip_kernel(FirParams P)
 {
     typedef typename Stage<IN>::T ST;
     typedef typename Wide<IN>::T WV;
@@ -487,6 +510,9 @@ __global__ __launch_bounds__(512, 4) void fir_strip_kernel(FirParams P)
     // STORE (P.dst != NULL) is a template parameter: with a run-time test around the stores the compiler
     // loses count of them and waits for them to complete before it lets the prefetched loads be used
     OUT *dst = (OUT *)P.dst + (size_t)tile * P.rows * 64 + lane;
+    // STREAM: window b's own rows start at lead_rows (at 0 for the stream's first window, which has no
+    // warm-up)
+    if (STREAM) dst += (size_t)(b > 0 ? P.lead_rows : 0) * 64;
     const double scale = SCALED ? P.scale[b] : 1.0;
     double s_re = 0.0, s_im = 0.0, s_sq = 0.0, c_re = 0.0, c_im = 0.0;
 
@@ -501,19 +527,27 @@ __global__ __launch_bounds__(512, 4) void fir_strip_kernel(FirParams P)
 #pragma unroll
         for (int q = 0; q < RQ; q++) {
             const IN *src = rows0 + (int64_t)q * P.ld + HALO - P.start;        // the row's sample 0
+            const int64_t row_at = (int64_t)(tile * 64 + w * RQ + q) * P.ld;   // ... as a stream sample
 #pragma unroll
             for (int k = 0; k < NPL; k++) {
                 int g = g0 + (lane + 64 * k) * SPL;
-                g = g < 0 ? 0 : (g > len - SPL ? len - SPL : g);
-                v[q][k] = __builtin_nontemporal_load((const WV *)(src + g));
+                if (STREAM) {
+                    int64_t ga = row_at + g;
+                    ga = ga < 0 ? 0 : (ga > P.n_total - SPL ? P.n_total - SPL : ga);
+                    v[q][k] = __builtin_nontemporal_load((const WV *)((const IN *)P.src + ga));
+                } else {
+                    g = g < 0 ? 0 : (g > len - SPL ? len - SPL : g);
+                    v[q][k] = __builtin_nontemporal_load((const WV *)(src + g));
+                }
             }
         }
 #pragma unroll
         for (int q = 0; q < RQ; q++) {
+            const int64_t row_at = (int64_t)(tile * 64 + w * RQ + q) * P.ld;
 #pragma unroll
             for (int k = 0; k < NPL; k++) {
                 const int i = lane + 64 * k, g = g0 + i * SPL;
-                const bool in = g >= 0 && g + SPL <= len;
+                const bool in = STREAM ? (row_at + g >= 0 && row_at + g + SPL <= P.n_total) : (g >= 0 && g + SPL <= len);
                 if (i < WPR) {
 #pragma unroll
                     for (int u = 0; u < SPL; u++)
@@ -535,8 +569,16 @@ __global__ __launch_bounds__(512, 4) void fir_strip_kernel(FirParams P)
             const int g = gn > len - SPL ? len - SPL : gn;
 #pragma unroll
             for (int q = 0; q < RQ; q++) {
-                const IN *src = rows0 + (int64_t)q * P.ld + HALO - P.start;
-                pre[q] = __builtin_nontemporal_load((const WV *)(src + g));
+                if (STREAM) {       // the next segment's samples follow in memory; only the stream ends
+                    // (wave-uniform row base + a 32-bit lane offset, clamped to the stream's last piece)
+                    const int64_t row_at = (int64_t)(tile * 64 + w * RQ + q) * P.ld;
+                    const int64_t room = P.n_total - SPL - row_at;
+                    const int lim = room > 0x7fffffff ? 0x7fffffff : (int)room;
+                    pre[q] = __builtin_nontemporal_load((const WV *)((const IN *)P.src + row_at + (gn > lim ? lim : gn)));
+                } else {
+                    const IN *src = rows0 + (int64_t)q * P.ld + HALO - P.start;
+                    pre[q] = __builtin_nontemporal_load((const WV *)(src + g));
+                }
             }
         }
         double are[OG], aim[OG];
@@ -544,7 +586,7 @@ __global__ __launch_bounds__(512, 4) void fir_strip_kernel(FirParams P)
         if (c == c_lo) { c_re = are[0]; c_im = aim[0]; }
         const int n_a = c * CH + w * OG;
         OUT *drow = dst + (size_t)n_a * 64;
-        if (c * CH + CH <= len && c * CH + CH <= rows) {
+        if (c * CH + CH <= len && (STREAM || c * CH + CH <= rows)) {
             // every output is valid, counted and stored once
 #pragma unroll
             for (int o = 0; o < OG; o++) {
@@ -554,9 +596,34 @@ __global__ __launch_bounds__(512, 4) void fir_strip_kernel(FirParams P)
                 if (STORE) put(drow + (size_t)o * 64, SCALED ? are[o] * scale : are[o], SCALED ? aim[o] * scale : aim[o]);
             }
             cnt += OG;
+            if (STREAM && STORE) {
+                // the successor's warm-up rows / the predecessor's tail rows (zone tests are wave-uniform)
+                OUT *nxt, *prv; bool has_nxt, has_prv;
+                neighbour_rows(P, lane, tile, nxt, prv, has_nxt, has_prv);
+                if (n_a >= len - P.lead_rows) {
+                    if (has_nxt) {
+#pragma unroll
+                        for (int o = 0; o < OG; o++)
+                            put(nxt + (size_t)(n_a + o) * 64, SCALED ? are[o] * scale : are[o], SCALED ? aim[o] * scale : aim[o]);
+                    }
+                } else if (n_a + OG > len - P.lead_rows) {
+#pragma unroll
+                    for (int o = 0; o < OG; o++)
+                        if (has_nxt && n_a + o >= len - P.lead_rows)
+                            put(nxt + (size_t)(n_a + o) * 64, SCALED ? are[o] * scale : are[o], SCALED ? aim[o] * scale : aim[o]);
+                }
+                if (n_a < P.tail_rows) {
+#pragma unroll
+                    for (int o = 0; o < OG; o++)
+                        if (has_prv && n_a + o < P.tail_rows)
+                            put(prv + (size_t)(n_a + o) * 64, SCALED ? are[o] * scale : are[o], SCALED ? aim[o] * scale : aim[o]);
+                }
+            }
         } else {
             // the chunk that holds the burst's end: outputs past it are zeros and do not count (the
             // bursts are equally long, so every test is wave-uniform)
+            OUT *nxt = nullptr, *prv = nullptr; bool has_nxt = false, has_prv = false;
+            if (STREAM && STORE) neighbour_rows(P, lane, tile, nxt, prv, has_nxt, has_prv);
 #pragma unroll
             for (int o = 0; o < OG; o++) {
                 const bool valid = n_a + o < len;
@@ -566,9 +633,17 @@ __global__ __launch_bounds__(512, 4) void fir_strip_kernel(FirParams P)
                     s_sq = __builtin_fma(di, di, __builtin_fma(dr, dr, s_sq));
                     cnt++;
                 }
-                if (STORE && n_a + o < rows)
+                if (STORE && !STREAM && n_a + o < rows)
                     put(drow + (size_t)o * 64, valid ? (SCALED ? are[o] * scale : are[o]) : 0.0,
                         valid ? (SCALED ? aim[o] * scale : aim[o]) : 0.0);
+                if (STORE && STREAM && valid) {
+                    // outputs past the segment's end belong to the next segment: nothing is stored for them
+                    put(drow + (size_t)o * 64, SCALED ? are[o] * scale : are[o], SCALED ? aim[o] * scale : aim[o]);
+                    if (has_nxt && n_a + o >= len - P.lead_rows)
+                        put(nxt + (size_t)(n_a + o) * 64, SCALED ? are[o] * scale : are[o], SCALED ? aim[o] * scale : aim[o]);
+                    if (has_prv && n_a + o < P.tail_rows)
+                        put(prv + (size_t)(n_a + o) * 64, SCALED ? are[o] * scale : are[o], SCALED ? aim[o] * scale : aim[o]);
+                }
             }
         }
         if (c + 1 == c_hi) break;
@@ -588,7 +663,11 @@ __global__ __launch_bounds__(512, 4) void fir_strip_kernel(FirParams P)
                 if (idx < RQ * HALO) myrows[q * stride + i] = keep[j];
             }
             if (lane < LPR) {
-                if (cn * CH + P.start + CH <= len) {
+                // nothing to mask: the new samples lie inside the burst (inside the stream: all but the
+                // last tile's rows can never reach its end)
+                const bool whole = STREAM ? (tile * 64 + 63 < P.B - 1 || (int64_t)(P.B - 1) * P.ld + cn * CH + P.start + CH <= P.n_total)
+                                          : (cn * CH + P.start + CH <= len);
+                if (whole) {
 #pragma unroll
                     for (int q = 0; q < RQ; q++) {
 #pragma unroll
@@ -596,9 +675,10 @@ __global__ __launch_bounds__(512, 4) void fir_strip_kernel(FirParams P)
                             myrows[q * stride + HALO + lane * SPL + u] = to_stage(wide_get(pre[q], u), isc);
                     }
                 } else {
-                    const bool in = gn + SPL <= len;
 #pragma unroll
                     for (int q = 0; q < RQ; q++) {
+                        const bool in = STREAM ? ((int64_t)(tile * 64 + w * RQ + q) * P.ld + gn + SPL <= P.n_total)
+                                               : (gn + SPL <= len);
 #pragma unroll
                         for (int u = 0; u < SPL; u++)
                             myrows[q * stride + HALO + lane * SPL + u] = in ? to_stage(wide_get(pre[q], u), isc) : ST{0, 0};
@@ -861,6 +941,7 @@ hipError_t launch_fir_stream_t(const FirParams &P, hipStream_t s)
         // strips over the interior chunks of the full tiles ...
         void (*ks)(FirParams) = P.dst ? (P.scale ? fir_strip_kernel<IN, OUT, OG, true, true> : fir_strip_kernel<IN, OUT, OG, false, true>)
                                       : fir_strip_kernel<IN, OUT, OG, false, false>;
+        if (P.stream_mode) ks = fir_strip_kernel<IN, OUT, OG, false, true, true>;     // capture mode: unscaled, stored
         hipError_t e = hipFuncSetAttribute((const void *)ks, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         // 78 KB of LDS and <= 128 VGPRs: two workgroups per CU, so that one's load / barrier phases fall
@@ -954,6 +1035,9 @@ static void fir_plan_strips(FirParams &P, int in_kind)
     const int esz = in_kind == DSP_IN_I16 ? 4 : 8;
     if (P.ld % spl || (P.start - (FIR_MT - 1)) % spl || ((uintptr_t)P.src & 15) || (P.ld * esz) % 16) return;
     if (P.len_all % spl || P.rows < P.len_all || P.start < 0) return;   // the bursts' ends fall on 16-byte pieces
+    if (P.stream_mode && (P.B % 64 || P.ld != P.len_all || P.n_total != (int64_t)P.B * P.ld || !P.dst || P.scale ||
+                          P.rows < P.lead_rows + P.len_all + P.tail_rows || P.lead_rows > P.len_all ||
+                          P.tail_rows > P.len_all)) { P.stream_mode = 0; return; }
     const int c0 = 0, c1 = P.nchunk;                                     // the strips cover every chunk
     const int nint = c1 - c0, full = P.B / 64;
     if (nint < 8 || full < 1) return;
@@ -975,11 +1059,22 @@ static void fir_plan_strips(FirParams &P, int in_kind)
     P.cps = best; P.c_int0 = c0; P.c_int1 = c1; P.strip_tiles = full;
     P.rec_full = 8 * ((nint + best - 1) / best) + n_edge;
     P.nrec = P.rec_full > P.nchunk ? P.rec_full : P.nchunk;
+    if (P.stream_mode) P.nrec = P.rec_full;         // every record is written: the stream's std merges them all
+}
+
+bool fir_stream_mode_plan(FirParams &P, int in_kind)
+{
+    if (!P.stream_mode) return false;
+    fir_plan_strips(P, in_kind);
+    if (!P.cps) P.stream_mode = 0;
+    return P.stream_mode != 0;
 }
 
 hipError_t launch_fir_tile(FirParams &P, int in_kind, hipStream_t s)
 {
+    const int want_stream_mode = P.stream_mode;
     fir_plan_strips(P, in_kind);
+    if (want_stream_mode && (!P.cps || !P.stream_mode)) return hipErrorInvalidValue;   // see fir_stream_mode_plan
     if (P.stream) {
         // the start of the zero-padded filter moves with the padding: none here (zeros are appended)
         if (in_kind == DSP_IN_I16) return launch_fir_stream_t<s2v, f2v>(P, s);

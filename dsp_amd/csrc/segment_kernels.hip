@@ -344,6 +344,22 @@ hipError_t launch_seg_windows(int S, int64_t n_total, int64_t seg_len, int64_t l
     return hipGetLastError();
 }
 
+// rows past a window's end, one 64-thread group per window (a few padding rows for most windows; the
+// first window has no warm-up and the last no tail, so theirs are `lead` / `tail` rows more)
+__global__ void seg_zero_past_k(float2 *__restrict__ tiles, int rows, const int *__restrict__ lens, int S)
+{
+    const int w = blockIdx.x;
+    if (w >= S) return;
+    float2 *col = tiles + (size_t)(w >> 6) * rows * 64 + (w & 63);
+    for (int r = lens[w] + threadIdx.x; r < rows; r += blockDim.x) col[(size_t)r * 64] = float2{0.f, 0.f};
+}
+
+hipError_t launch_seg_zero_past(void *tiles, int rows, const int *lens, int S, hipStream_t s)
+{
+    hipLaunchKernelGGL(seg_zero_past_k, dim3(S), dim3(64), 0, s, (float2 *)tiles, rows, lens, S);
+    return hipGetLastError();
+}
+
 hipError_t launch_seg_lead_copy(void *tiles, int rows, const int64_t *starts, int S, int lead, hipStream_t s)
 {
     const int ntiles = (S + 63) / 64;

@@ -281,12 +281,16 @@ def test_capture_int16_pointer_alignment(ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_keep", [100 * 2048, 130 * 2048 - 700])
+@pytest.mark.parametrize("n_keep", [100 * 2048, 130 * 2048 - 700, 128 * 2048, 192 * 2048])
 def test_gpu_shared_warmup_rows_bit_identical(oracle, ctx, n_keep):
     """More than 64 windows with the matched filter: a window's warm-up rows come from its
     predecessor (stored by the predecessor's filter workgroup, or copied afterwards) instead of being
     filtered again.  All three ways give the same bits; the result follows the oracle as closely as
-    the per-window filter does (test_gpu_segmented_int16_with_matched_filter)."""
+    the per-window filter does (test_gpu_segmented_int16_with_matched_filter).
+    A whole number of 64-window tiles of whole segments (the last two sizes) takes, with lead_copy 0,
+    the segment-wise pass of the persistent filter kernel (fir_strip_kernel STREAM: every stream sample
+    filtered once, stored into its own window and into the neighbours' warm-up / tail rows) -- the
+    same bits again."""
     import dsp_amd
     q, x, h = make_stream(n_keep // SPS + 64, seed=23)
     x = x[:n_keep]
