@@ -426,7 +426,13 @@ static int count_nonnull(std::initializer_list<const void *> l)
     return n;
 }
 
-int dsp_sync_tiles_dev(dsp_ctx *c, const dsp_sync_args *a)
+// x_tile_rows / x_tile0: SyncParams (segment-parallel mode lays its windows out overlapping; 0 / NULL for
+// the C-ABI's separate tiles)
+static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, const void *x_tile0);
+
+int dsp_sync_tiles_dev(dsp_ctx *c, const dsp_sync_args *a) { return sync_tiles_run(c, a, 0, nullptr); }
+
+static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, const void *x_tile0)
 {
     if (!c || !a) return fail(DSP_E_ARG, "ctx/args is NULL");
     if (a->B < 0 || a->B > (1 << 30)) return fail(DSP_E_ARG, "sync: bad B");
@@ -449,6 +455,7 @@ int dsp_sync_tiles_dev(dsp_ctx *c, const dsp_sync_args *a)
     memset(&P, 0, sizeof(P));
     P.x = a->x; P.lens = a->lens; P.scale = a->scale;
     P.B = (int)a->B; P.in_rows = (int)a->in_rows; P.len_all = (int)a->N; P.sps = sps;
+    P.x_tile_rows = x_tile_rows > 0 ? x_tile_rows : P.in_rows; P.x_tile0 = x_tile0;
     P.alpha = a->alpha; P.mu0 = a->mu0; P.mu0_per = a->variant == DSP_GARDNER2 ? a->mu0_per : nullptr; P.half_len = a->variant == 2 ? 0 : a->interp_half_len;
     if (fll) dsp_fll_gains(a->Bn, a->y, &P.kp, &P.ki);
     P.i0 = a->i0; P.fll_in = a->fll_state_in; P.fll_out = a->fll_state_out;
@@ -1379,7 +1386,14 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
     small.cap = (size_t)64 * 1024 + (size_t)S * 96;
     HIP_TRY(ctx_scratch(c, 5, small.cap, (void **)&small.base));
     d_starts.p = small.take((size_t)S * 8); d_lens.p = small.take((size_t)S * 4);
-    HIP_TRY(ctx_scratch(c, 0, (size_t)ntiles * rows * 64 * 8, &d_tiles.p));
+    // window tiles [ntiles][rows][64], or (by_segment below) lane-major segment tiles [ntiles][seg][64] + the
+    // rows behind the last one + tile 0's windows: the buffer serves either
+    const int64_t pad_rows = rows - lead - seg > 0 ? rows - lead - seg : 0;
+    {
+        const size_t win_bytes = (size_t)ntiles * rows * 64 * 8;
+        const size_t seg_bytes = ((size_t)ntiles * seg + pad_rows + rows) * 64 * 8;
+        HIP_TRY(ctx_scratch(c, 0, win_bytes > seg_bytes ? win_bytes : seg_bytes, &d_tiles.p));
+    }
     if (a->mu) HIP_TRY(ctx_scratch(c, 1, (size_t)ntiles * out_rows * 64 * 4, &d_mu.p));
     HIP_TRY(ctx_scratch(c, 2, (size_t)ntiles * out_rows * 64 * 4, &d_pos.p));
     HIP_TRY(ctx_scratch(c, 3, (size_t)ntiles * out_rows * 64, &d_dec.p));
@@ -1407,32 +1421,38 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
                               a->h ? nullptr : d_c64.p, st));
         in_scale = d_peak.as<float>() + 1;
     }
+    // (a) the stream cut into its segments, each filtered once by the persistent strip kernel into lane-major
+    //     segment tiles: window (tile t, lane l) = segment l * ntiles + t, its warm-up rows are the rows in
+    //     front of tile t (the same lane's previous segment) and its tail the rows behind it ...
+    FirParams Q;
+    memset(&Q, 0, sizeof(Q));
+    bool by_segment = false;
+    if (a->h && c->fir_stream == 2 && c->lead_copy == 0 && S % 64 == 0 && n == (int64_t)S * seg && lead <= seg &&
+        tail <= seg && seg < (1 << 30) && fir_plan(a->in_kind, a->n_taps, (int)seg, Q, true) && Q.stream) {
+        Q.stream_mode = 1; Q.strip_ok = 1; Q.n_cu = c->n_cu;
+        Q.src = a->x; Q.n_total = n; Q.ld = seg; Q.len_all = (int)seg; Q.B = S;
+        Q.h = a->h; Q.M = a->n_taps; Q.start = (a->n_taps - 1) / 2; Q.h_pad = c->fir_taps;
+        Q.in_scale = in_scale; Q.dst = d_tiles.p; Q.rows = (int)seg;
+        by_segment = fir_stream_mode_plan(Q, a->in_kind);
+    }
+    const int map_tiles = by_segment ? (int)ntiles : 0;
+    // the recurrence kernel's view of the windows: rows of tile t start x_tile_rows * t rows after win_x
+    const void *win_x = by_segment ? (const void *)((const char *)d_tiles.p - (ptrdiff_t)lead * 64 * 8) : d_tiles.p;
+    void *win_tile0 = by_segment ? (void *)((char *)d_tiles.p + ((size_t)ntiles * seg + pad_rows) * 64 * 8) : nullptr;
+    const int win_stride = by_segment ? (int)seg : 0;
     HIP_TRY(launch_seg_windows(S, n, seg, lead, tail, d_starts.as<int64_t>(), d_lens.as<int>(), d_lo.as<int>(),
-                               d_hi.as<int>(), st));
+                               d_hi.as<int>(), st, map_tiles));
     const double *d_scale = nullptr;
     if (a->h) {
         // ONE filter pass over the overlapping windows: unscaled fl32(y) into the tiles, statistics
         // over each window's own samples only (the windows' shares partition the stream), merged
         // into the np.std of the whole filtered stream; 1/std is applied by the recurrence kernel
-        FirParams Q;
-        memset(&Q, 0, sizeof(Q));
-        // (a) the stream cut into its segments, each filtered once by the persistent strip kernel, every
-        //     output stored into its own window and into the neighbours' warm-up / tail rows ...
-        bool by_segment = false;
-        if (c->fir_stream == 2 && c->lead_copy == 0 && S % 64 == 0 && n == (int64_t)S * seg && lead <= seg &&
-            tail <= seg && fir_plan(a->in_kind, a->n_taps, (int)seg, Q, true) && Q.stream) {
-            Q.stream_mode = 1; Q.strip_ok = 1; Q.n_cu = c->n_cu;
-            Q.lead_rows = (int)lead; Q.tail_rows = (int)tail;
-            Q.src = a->x; Q.n_total = n; Q.ld = seg; Q.len_all = (int)seg; Q.B = S;
-            Q.h = a->h; Q.M = a->n_taps; Q.start = (a->n_taps - 1) / 2; Q.h_pad = c->fir_taps;
-            Q.in_scale = in_scale; Q.dst = d_tiles.p; Q.rows = (int)rows;
-            by_segment = fir_stream_mode_plan(Q, a->in_kind);
-        }
         if (by_segment) {
             HIP_TRY(ctx_scratch(c, 6, (size_t)S * (Q.nchunk + 8) * 32, &d_ws.p));
             Q.stats = d_ws.as<double>();
             HIP_TRY(launch_fir_tile(Q, a->in_kind, st));
-            HIP_TRY(launch_seg_zero_past(d_tiles.p, (int)rows, d_lens.as<int>(), S, st));
+            HIP_TRY(launch_seg_edge_tiles(d_tiles.p, map_tiles, seg, n, d_starts.as<int64_t>(), d_lens.as<int>(), win_tile0,
+                                          (int)rows, (int)pad_rows, st));
         } else {
             // (b) ... or the overlapping windows themselves, chunk by chunk
             memset(&Q, 0, sizeof(Q));
@@ -1464,27 +1484,27 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
 
     // ---- initial timing phase per window (strobe energy), unless the caller fixes mu0 ------------
     if (a->acquire) {
-        HIP_TRY(launch_seg_phase(d_tiles.p, (int)rows, d_lens.as<int>(), S, sps, DSP_ACQUIRE_SYMBOLS,
-                                 d_mu0.as<double>(), st));
+        HIP_TRY(launch_seg_phase(win_x, (int)rows, d_lens.as<int>(), S, sps, DSP_ACQUIRE_SYMBOLS,
+                                 d_mu0.as<double>(), st, win_stride, win_tile0));
     }
 
     // ---- the batched recurrence over the windows -------------------------------------------
     dsp_sync_args sa;
     memset(&sa, 0, sizeof(sa));
     sa.mu0_per = a->acquire ? d_mu0.as<double>() : nullptr;
-    sa.x = d_tiles.p; sa.dtype = DSP_C64; sa.variant = DSP_GARDNER2; sa.B = S; sa.N = Nw; sa.in_rows = rows;
+    sa.x = win_x; sa.dtype = DSP_C64; sa.variant = DSP_GARDNER2; sa.B = S; sa.N = Nw; sa.in_rows = rows;
     sa.lens = d_lens.as<int32_t>(); sa.scale = d_scale; sa.sps = sps; sa.alpha = a->alpha; sa.mu0 = a->mu0; sa.do_fll = 1;
     sa.Bn = a->Bn; sa.y = a->y; sa.mu = a->mu ? d_mu.p : nullptr; sa.pos = d_pos.p; sa.dec = d_dec.as<uint8_t>(); sa.freq = a->freq ? d_freq.p : nullptr;
     sa.out_rows = out_rows; sa.n_out = d_nout.as<int32_t>(); sa.status = d_status.as<int32_t>();
     {
-        int rc = dsp_sync_tiles_dev(c, &sa);
+        int rc = sync_tiles_run(c, &sa, win_stride, win_tile0);
         if (rc != DSP_OK) return rc;
     }
 
     // ---- stitch ----------------------------------------------------------------------------
     SegParams G;
     memset(&G, 0, sizeof(G));
-    G.S = S; G.sps = sps; G.out_rows = (int)out_rows; G.n_total = n; G.seg_len = seg;
+    G.S = S; G.sps = sps; G.out_rows = (int)out_rows; G.n_total = n; G.seg_len = seg; G.map_tiles = map_tiles;
     G.starts = d_starts.as<int64_t>(); G.n_out = d_nout.as<int>(); G.mu = a->mu ? d_mu.p : nullptr; G.pos = d_pos.p; G.dec = d_dec.as<uint8_t>();
     G.freq = a->freq ? d_freq.p : nullptr;
     G.j0 = d_j0.as<int>(); G.j1 = d_j1.as<int>(); G.p_last = d_pl.as<double>(); G.rot = d_rot.as<int>();
@@ -1500,8 +1520,9 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
         HIP_TRY(hipMemcpyAsync(info.data(), d_j0.p, (size_t)S * 16, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         for (size_t s = 0; s < (size_t)S; s++) {
-            a->seg_info[4 * s] = info[s]; a->seg_info[4 * s + 1] = info[S + s];
-            a->seg_info[4 * s + 2] = info[2 * (size_t)S + s]; a->seg_info[4 * s + 3] = info[3 * (size_t)S + s];
+            const size_t at = (size_t)seg_slot((int)s, map_tiles);           // the device arrays are in slot order
+            a->seg_info[4 * s] = info[at]; a->seg_info[4 * s + 1] = info[S + at];
+            a->seg_info[4 * s + 2] = info[2 * (size_t)S + at]; a->seg_info[4 * s + 3] = info[3 * (size_t)S + at];
         }
     }
     HIP_TRY(hipStreamSynchronize(st));

@@ -23,6 +23,8 @@ struct SyncParams {
     const int *lens;          // [B] valid samples per burst, or NULL -> len_all
     const double *scale;      // [B] per-burst input scale (1/std), or NULL -> 1.0
     int B, in_rows, len_all, sps;
+    int x_tile_rows;          // rows between row 0 of consecutive tiles (== in_rows unless the tiles' windows overlap)
+    const void *x_tile0;      // tile 0's rows if they live elsewhere, or NULL
     // Gardner
     double alpha;             // gardner2: alpha; ted: delta_mu
     double mu0;
@@ -93,9 +95,9 @@ struct FirParams {
     int waves;                // waves per workgroup: 0 = auto (8 where the chunk divides), 4 = always 4
     int stream;               // set by fir_plan: 1 = fir_stream_kernel (<= 41 taps, float32 staging)
     int strip_ok;             // in: launch_fir_tile may use the persistent fir_strip_kernel
-    int stream_mode;          // in: the bursts are the consecutive segments of one stream of n_total samples
-                              //     (fir_strip_kernel STREAM; cleared by launch_fir_tile if it cannot serve)
-    int lead_rows, tail_rows; // in (stream_mode): warm-up rows / tail rows of a window in the tiles
+    int stream_mode;          // in: the bursts are the consecutive segments of one stream of n_total samples,
+                              //     lane l of tile t = segment l * ntiles + t, rows == len_all == ld
+                              //     (fir_strip_kernel STREAM; cleared by fir_stream_mode_plan if it cannot serve)
     int n_cu;                 // in: compute units of the device (strip planning)
     // set by launch_fir_tile:
     int cps;                  // chunks per strip of fir_strip_kernel, 0 = chunk-per-workgroup kernels only
@@ -149,14 +151,27 @@ struct SegParams {
     double *p_last;           // [S] stream position of row j1 - 1
     int *rot;                 // [S] quadrant rotation of each window relative to its predecessor, then cumulative
     int64_t *off;             // [S + 1] output offset of each window's first kept symbol
+    // Every per-window array above is indexed by the window's SLOT = tile * 64 + lane in the recurrence
+    // kernel.  map_tiles == 0: slot == window; > 0 (lane-major, S == 64 * map_tiles): window s sits in
+    // lane s / map_tiles of tile s % map_tiles, so that a lane's windows in consecutive tiles are
+    // consecutive segments of the stream.
+    int map_tiles;
 };
+static inline __host__ __device__ int seg_slot(int s, int map_tiles)
+{
+    return map_tiles > 0 ? (s % map_tiles) * 64 + s / map_tiles : s;
+}
 hipError_t launch_seg_windows(int S, int64_t n_total, int64_t seg_len, int64_t lead, int64_t tail,
-                              int64_t *starts, int *lens, int *own_lo, int *own_hi, hipStream_t s);
+                              int64_t *starts, int *lens, int *own_lo, int *own_hi, hipStream_t s, int map_tiles = 0);
+// Lane-major segment tiles (fir_strip_kernel STREAM: [map_tiles][seg_len][64] at `tiles`): the windows of
+// tile 0 gathered into a tile of their own (`tile0`, win_rows rows: their warm-up rows are the ends of
+// other lanes' last segments, and the stream's first window has none) and the pad_rows rows behind the
+// last tile (the starts of the next lanes' first segments; zeros past the stream's end)
+hipError_t launch_seg_edge_tiles(void *tiles, int map_tiles, int64_t seg_len, int64_t n_total, const int64_t *starts,
+                                 const int *lens, void *tile0, int win_rows, int pad_rows, hipStream_t s);
 hipError_t launch_seg_lead_copy(void *tiles, int rows, const int64_t *starts, int S, int lead, hipStream_t s);
-// zero rows [lens[w], rows) of every window's lane (the rows the stream-mode filter pass does not write)
-hipError_t launch_seg_zero_past(void *tiles, int rows, const int *lens, int S, hipStream_t s);
 hipError_t launch_seg_phase(const void *tiles, int rows, const int *lens, int S, int sps, int n_sym, double *mu0,
-                            hipStream_t s);
+                            hipStream_t s, int x_tile_rows = 0, const void *x_tile0 = nullptr);
 hipError_t launch_seg_stitch(const SegParams &P, int overlap_vote, hipStream_t s);
 hipError_t launch_seg_gather(const SegParams &P, uint8_t *dec_out, float *mu_out, float *freq_out,
                              int64_t capacity, hipStream_t s);

@@ -457,31 +457,15 @@ template <> struct Wide<s2v> { typedef short T __attribute__((ext_vector_type(8)
 __device__ __forceinline__ f2v wide_get(const Wide<f2v>::T &v, int i) { return i ? f2v{v.z, v.w} : f2v{v.x, v.y}; }
 __device__ __forceinline__ s2v wide_get(const Wide<s2v>::T &v, int i) { return s2v{v[2 * i], v[2 * i + 1]}; }
 
-// fir_strip_kernel STREAM: where lane `lane` of tile `tile` (window b) also stores its outputs -- its
-// successor's warm-up rows and its predecessor's tail rows, as pointers that take the output index n
-// directly.  Worked out inside the chunks that need them (the lane index goes through an empty asm so the
-// compiler cannot hoist the arithmetic out of the chunk loop and hold four more registers across it).
-template <typename OUT>
-__device__ __forceinline__ void neighbour_rows(const FirParams &P, int lane, int tile, OUT *&nxt, OUT *&prv, bool &has_nxt,
-                                               bool &has_prv)
-{
-    asm volatile("" : "+v"(lane));
-    const int b = tile * 64 + lane, lead = P.lead_rows;
-    has_nxt = b + 1 < P.B && lead > 0;
-    has_prv = b > 0 && P.tail_rows > 0;
-    // successor's row n - (len - lead); predecessor's row (start of its own rows) + len + n
-    nxt = (OUT *)P.dst + (size_t)((b + 1) >> 6) * P.rows * 64 + ((b + 1) & 63) - (ptrdiff_t)(P.len_all - lead) * 64;
-    prv = (OUT *)P.dst + (size_t)((b - 1) >> 6) * P.rows * 64 + ((b - 1) & 63) + (ptrdiff_t)((b - 1 > 0 ? lead : 0) + P.len_all) * 64;
-}
-
-// STREAM: the "bursts" are the consecutive segments of ONE long stream (segment-parallel capture mode;
-// burst b = stream samples [b * ld, (b + 1) * ld), len_all == ld).  A window then sees its true
-// neighbours across the segment edges and zeros only beyond the stream's two ends, and every output
-// goes to up to three places in the window tiles the recurrence kernel reads: the segment's own
-// window (rows own_row0 + n), the successor's warm-up rows (the last `lead_rows` outputs) and the
-// predecessor's tail rows (the first `tail_rows` outputs).
+// STREAM: the "bursts" are the consecutive segments of ONE long stream (segment-parallel capture mode):
+// segment g = stream samples [g * ld, (g + 1) * ld), len_all == ld, and lane l of tile t is segment
+// l * ntiles + t (lane-major), so that in the output -- plain tiles of `rows` == ld rows, one after the
+// other -- the rows before a tile are, lane by lane, the end of each lane's preceding segment and the rows
+// after it the start of the following one: a window with warm-up and tail is a row range of that buffer
+// and every filtered sample is stored exactly once.  A segment's window sees its true neighbours across
+// the segment edges and zeros only beyond the stream's two ends.
 template <typename IN, typename OUT, int OG, bool SCALED, bool STORE, bool STREAM = false>
-__global__ __launch_bounds__(512, STREAM ? 2 : 4) void fir_strip_kernel(FirParams P)
+__global__ __launch_bounds__(512, 4) void fir_strip_kernel(FirParams P)
 {
     typedef typename Stage<IN>::T ST;
     typedef typename Wide<IN>::T WV;
@@ -506,13 +490,12 @@ __global__ __launch_bounds__(512, STREAM ? 2 : 4) void fir_strip_kernel(FirParam
     ST *myrows = xs + w * RQ * stride;
 
     // this lane's burst: output row pointer, scale, statistics
-    const int b = tile * 64 + lane;
+    const int ntiles = gridDim.y;
+    const int b = STREAM ? lane * ntiles + tile : tile * 64 + lane;
+    auto row_burst = [&](int q) { return STREAM ? (w * RQ + q) * ntiles + tile : tile * 64 + w * RQ + q; };
     // STORE (P.dst != NULL) is a template parameter: with a run-time test around the stores the compiler
     // loses count of them and waits for them to complete before it lets the prefetched loads be used
     OUT *dst = (OUT *)P.dst + (size_t)tile * P.rows * 64 + lane;
-    // STREAM: window b's own rows start at lead_rows (at 0 for the stream's first window, which has no
-    // warm-up)
-    if (STREAM) dst += (size_t)(b > 0 ? P.lead_rows : 0) * 64;
     const double scale = SCALED ? P.scale[b] : 1.0;
     double s_re = 0.0, s_im = 0.0, s_sq = 0.0, c_re = 0.0, c_im = 0.0;
 
@@ -527,7 +510,7 @@ __global__ __launch_bounds__(512, STREAM ? 2 : 4) void fir_strip_kernel(FirParam
 #pragma unroll
         for (int q = 0; q < RQ; q++) {
             const IN *src = rows0 + (int64_t)q * P.ld + HALO - P.start;        // the row's sample 0
-            const int64_t row_at = (int64_t)(tile * 64 + w * RQ + q) * P.ld;   // ... as a stream sample
+            const int64_t row_at = (int64_t)row_burst(q) * P.ld;               // ... as a stream sample
 #pragma unroll
             for (int k = 0; k < NPL; k++) {
                 int g = g0 + (lane + 64 * k) * SPL;
@@ -543,7 +526,7 @@ __global__ __launch_bounds__(512, STREAM ? 2 : 4) void fir_strip_kernel(FirParam
         }
 #pragma unroll
         for (int q = 0; q < RQ; q++) {
-            const int64_t row_at = (int64_t)(tile * 64 + w * RQ + q) * P.ld;
+            const int64_t row_at = (int64_t)row_burst(q) * P.ld;
 #pragma unroll
             for (int k = 0; k < NPL; k++) {
                 const int i = lane + 64 * k, g = g0 + i * SPL;
@@ -571,7 +554,7 @@ __global__ __launch_bounds__(512, STREAM ? 2 : 4) void fir_strip_kernel(FirParam
             for (int q = 0; q < RQ; q++) {
                 if (STREAM) {       // the next segment's samples follow in memory; only the stream ends
                     // (wave-uniform row base + a 32-bit lane offset, clamped to the stream's last piece)
-                    const int64_t row_at = (int64_t)(tile * 64 + w * RQ + q) * P.ld;
+                    const int64_t row_at = (int64_t)row_burst(q) * P.ld;
                     const int64_t room = P.n_total - SPL - row_at;
                     const int lim = room > 0x7fffffff ? 0x7fffffff : (int)room;
                     pre[q] = __builtin_nontemporal_load((const WV *)((const IN *)P.src + row_at + (gn > lim ? lim : gn)));
@@ -586,7 +569,7 @@ __global__ __launch_bounds__(512, STREAM ? 2 : 4) void fir_strip_kernel(FirParam
         if (c == c_lo) { c_re = are[0]; c_im = aim[0]; }
         const int n_a = c * CH + w * OG;
         OUT *drow = dst + (size_t)n_a * 64;
-        if (c * CH + CH <= len && (STREAM || c * CH + CH <= rows)) {
+        if (c * CH + CH <= len && c * CH + CH <= rows) {
             // every output is valid, counted and stored once
 #pragma unroll
             for (int o = 0; o < OG; o++) {
@@ -596,34 +579,9 @@ __global__ __launch_bounds__(512, STREAM ? 2 : 4) void fir_strip_kernel(FirParam
                 if (STORE) put(drow + (size_t)o * 64, SCALED ? are[o] * scale : are[o], SCALED ? aim[o] * scale : aim[o]);
             }
             cnt += OG;
-            if (STREAM && STORE) {
-                // the successor's warm-up rows / the predecessor's tail rows (zone tests are wave-uniform)
-                OUT *nxt, *prv; bool has_nxt, has_prv;
-                neighbour_rows(P, lane, tile, nxt, prv, has_nxt, has_prv);
-                if (n_a >= len - P.lead_rows) {
-                    if (has_nxt) {
-#pragma unroll
-                        for (int o = 0; o < OG; o++)
-                            put(nxt + (size_t)(n_a + o) * 64, SCALED ? are[o] * scale : are[o], SCALED ? aim[o] * scale : aim[o]);
-                    }
-                } else if (n_a + OG > len - P.lead_rows) {
-#pragma unroll
-                    for (int o = 0; o < OG; o++)
-                        if (has_nxt && n_a + o >= len - P.lead_rows)
-                            put(nxt + (size_t)(n_a + o) * 64, SCALED ? are[o] * scale : are[o], SCALED ? aim[o] * scale : aim[o]);
-                }
-                if (n_a < P.tail_rows) {
-#pragma unroll
-                    for (int o = 0; o < OG; o++)
-                        if (has_prv && n_a + o < P.tail_rows)
-                            put(prv + (size_t)(n_a + o) * 64, SCALED ? are[o] * scale : are[o], SCALED ? aim[o] * scale : aim[o]);
-                }
-            }
         } else {
             // the chunk that holds the burst's end: outputs past it are zeros and do not count (the
             // bursts are equally long, so every test is wave-uniform)
-            OUT *nxt = nullptr, *prv = nullptr; bool has_nxt = false, has_prv = false;
-            if (STREAM && STORE) neighbour_rows(P, lane, tile, nxt, prv, has_nxt, has_prv);
 #pragma unroll
             for (int o = 0; o < OG; o++) {
                 const bool valid = n_a + o < len;
@@ -633,17 +591,9 @@ __global__ __launch_bounds__(512, STREAM ? 2 : 4) void fir_strip_kernel(FirParam
                     s_sq = __builtin_fma(di, di, __builtin_fma(dr, dr, s_sq));
                     cnt++;
                 }
-                if (STORE && !STREAM && n_a + o < rows)
+                if (STORE && n_a + o < rows)
                     put(drow + (size_t)o * 64, valid ? (SCALED ? are[o] * scale : are[o]) : 0.0,
                         valid ? (SCALED ? aim[o] * scale : aim[o]) : 0.0);
-                if (STORE && STREAM && valid) {
-                    // outputs past the segment's end belong to the next segment: nothing is stored for them
-                    put(drow + (size_t)o * 64, SCALED ? are[o] * scale : are[o], SCALED ? aim[o] * scale : aim[o]);
-                    if (has_nxt && n_a + o >= len - P.lead_rows)
-                        put(nxt + (size_t)(n_a + o) * 64, SCALED ? are[o] * scale : are[o], SCALED ? aim[o] * scale : aim[o]);
-                    if (has_prv && n_a + o < P.tail_rows)
-                        put(prv + (size_t)(n_a + o) * 64, SCALED ? are[o] * scale : are[o], SCALED ? aim[o] * scale : aim[o]);
-                }
             }
         }
         if (c + 1 == c_hi) break;
@@ -665,7 +615,7 @@ __global__ __launch_bounds__(512, STREAM ? 2 : 4) void fir_strip_kernel(FirParam
             if (lane < LPR) {
                 // nothing to mask: the new samples lie inside the burst (inside the stream: all but the
                 // last tile's rows can never reach its end)
-                const bool whole = STREAM ? (tile * 64 + 63 < P.B - 1 || (int64_t)(P.B - 1) * P.ld + cn * CH + P.start + CH <= P.n_total)
+                const bool whole = STREAM ? (tile + 1 < ntiles || (int64_t)(P.B - 1) * P.ld + cn * CH + P.start + CH <= P.n_total)
                                           : (cn * CH + P.start + CH <= len);
                 if (whole) {
 #pragma unroll
@@ -677,7 +627,7 @@ __global__ __launch_bounds__(512, STREAM ? 2 : 4) void fir_strip_kernel(FirParam
                 } else {
 #pragma unroll
                     for (int q = 0; q < RQ; q++) {
-                        const bool in = STREAM ? ((int64_t)(tile * 64 + w * RQ + q) * P.ld + gn + SPL <= P.n_total)
+                        const bool in = STREAM ? ((int64_t)row_burst(q) * P.ld + gn + SPL <= P.n_total)
                                                : (gn + SPL <= len);
 #pragma unroll
                         for (int u = 0; u < SPL; u++)
@@ -1036,8 +986,7 @@ static void fir_plan_strips(FirParams &P, int in_kind)
     if (P.ld % spl || (P.start - (FIR_MT - 1)) % spl || ((uintptr_t)P.src & 15) || (P.ld * esz) % 16) return;
     if (P.len_all % spl || P.rows < P.len_all || P.start < 0) return;   // the bursts' ends fall on 16-byte pieces
     if (P.stream_mode && (P.B % 64 || P.ld != P.len_all || P.n_total != (int64_t)P.B * P.ld || !P.dst || P.scale ||
-                          P.rows < P.lead_rows + P.len_all + P.tail_rows || P.lead_rows > P.len_all ||
-                          P.tail_rows > P.len_all)) { P.stream_mode = 0; return; }
+                          P.rows != P.len_all)) { P.stream_mode = 0; return; }
     const int c0 = 0, c1 = P.nchunk;                                     // the strips cover every chunk
     const int nint = c1 - c0, full = P.B / 64;
     if (nint < 8 || full < 1) return;

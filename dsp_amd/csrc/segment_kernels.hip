@@ -37,24 +37,25 @@ __device__ __forceinline__ unsigned rot_quadrant(unsigned q, int r)
 
 __global__ void seg_windows_k(int S, int64_t n_total, int64_t seg_len, int64_t lead, int64_t tail,
                               int64_t *__restrict__ starts, int *__restrict__ lens,
-                              int *__restrict__ own_lo, int *__restrict__ own_hi)
+                              int *__restrict__ own_lo, int *__restrict__ own_hi, int map_tiles)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
+    const int at = seg_slot(s, map_tiles);
     int64_t st = (int64_t)s * seg_len - lead;
     if (st < 0) st = 0;
     int64_t en = (int64_t)(s + 1) * seg_len + tail;
     if (en > n_total || s == S - 1) en = n_total;
-    starts[s] = st;
-    lens[s] = (int)(en - st);
+    starts[at] = st;
+    lens[at] = (int)(en - st);
     // the segment's own samples inside its window (the partition the stream statistics run over)
     int64_t o_hi = (int64_t)(s + 1) * seg_len;
     if (o_hi > n_total) o_hi = n_total;
-    if (own_lo) own_lo[s] = (int)((int64_t)s * seg_len - st);
-    if (own_hi) own_hi[s] = (int)(o_hi - st);
+    if (own_lo) own_lo[at] = (int)((int64_t)s * seg_len - st);
+    if (own_hi) own_hi[at] = (int)(o_hi - st);
 }
 
-// rows of a tiled float array of window s
+// rows of a tiled float array of the window in slot s
 __device__ __forceinline__ float tile_f32(const void *base, int out_rows, int s, int row)
 {
     return ((const float *)base)[((size_t)(s >> 6) * out_rows + row) * 64 + (s & 63)];
@@ -64,7 +65,7 @@ __device__ __forceinline__ unsigned tile_u8(const uint8_t *base, int out_rows, i
     return base[((size_t)(s >> 6) * out_rows + row) * 64 + (s & 63)];
 }
 
-// Stream position of symbol row r of window s: row 0 is the window's first sample
+// Stream position of symbol row r of the window in slot s: row 0 is the window's first sample
 // (gardner2.py:59), row r >= 1 is k + mu of the iteration that produced it (gardner2.py:95), which
 // the recurrence kernel wrote to row r - 1 of `pos`.  Positions grow by sps + (mu change) per
 // row, so they are strictly increasing and a binary search finds the seams.
@@ -90,32 +91,34 @@ __global__ __launch_bounds__(64) void seg_scan_k(SegParams P)
 {
     const int s = blockIdx.x * 64 + threadIdx.x;
     if (s >= P.S) return;
-    const int n = P.n_out[s];
+    const int at = seg_slot(s, P.map_tiles);
+    const int n = P.n_out[at];
     int j1 = n;
-    if (s != P.S - 1) j1 = rows_below(P, s, n, (double)(s + 1) * (double)P.seg_len, true);
-    P.j1[s] = j1;
-    P.p_last[s] = j1 > 0 ? row_position(P, s, j1 - 1) : -1.0e300;
+    if (s != P.S - 1) j1 = rows_below(P, at, n, (double)(s + 1) * (double)P.seg_len, true);
+    P.j1[at] = j1;
+    P.p_last[at] = j1 > 0 ? row_position(P, at, j1 - 1) : -1.0e300;
 }
 
 __global__ __launch_bounds__(64) void seg_range_k(SegParams P, int vote_len)
 {
     const int s = blockIdx.x * 64 + threadIdx.x;
     if (s >= P.S) return;
-    const int j1 = P.j1[s];
+    const int at = seg_slot(s, P.map_tiles), before = seg_slot(s > 0 ? s - 1 : 0, P.map_tiles);
+    const int j1 = P.j1[at];
     int j0 = 0, rot = 0;
     if (s > 0) {
         // the share starts with the first symbol more than half a symbol after the predecessor's last
-        j0 = rows_below(P, s, j1, P.p_last[s - 1] + 0.5 * (double)P.sps, false);
+        j0 = rows_below(P, at, j1, P.p_last[before] + 0.5 * (double)P.sps, false);
         // rows j0-1-m of this window and j1'-1-m of the predecessor are the same symbols
-        const int jp = P.j1[s - 1];
+        const int jp = P.j1[before];
         int V = vote_len;
         if (V > j0) V = j0;
         if (V > jp) V = jp;
         // every pair of decisions agrees under exactly one of the four turns: one pass, four counters
         int agree[4] = {0, 0, 0, 0};
         for (int m = 0; m < V; m++) {
-            const unsigned a = tile_u8(P.dec, P.out_rows, s, j0 - 1 - m);
-            const unsigned b = tile_u8(P.dec, P.out_rows, s - 1, jp - 1 - m);
+            const unsigned a = tile_u8(P.dec, P.out_rows, at, j0 - 1 - m);
+            const unsigned b = tile_u8(P.dec, P.out_rows, before, jp - 1 - m);
 #pragma unroll
             for (int r4 = 0; r4 < 4; r4++) agree[r4] += rot_quadrant(a, r4) == b;
         }
@@ -125,8 +128,8 @@ __global__ __launch_bounds__(64) void seg_range_k(SegParams P, int vote_len)
             if (agree[r4] > best) { best = agree[r4]; rot = r4; }
     }
     if (j0 > j1) j0 = j1;
-    P.j0[s] = j0;
-    P.rot[s] = rot;
+    P.j0[at] = j0;
+    P.rot[at] = rot;
 }
 
 // exclusive scan of the share sizes and running rotation (one workgroup; S <= a few 10^5)
@@ -138,7 +141,10 @@ __global__ __launch_bounds__(1024) void seg_offsets_k(SegParams P)
     const int per = (P.S + 1023) / 1024;
     const int lo = t * per, hi = (lo + per < P.S) ? lo + per : P.S;
     long long c = 0; int r = 0;
-    for (int s = lo; s < hi; s++) { c += P.j1[s] - P.j0[s]; r += P.rot[s]; }
+    for (int s = lo; s < hi; s++) {
+        const int at = seg_slot(s, P.map_tiles);
+        c += P.j1[at] - P.j0[at]; r += P.rot[at];
+    }
     cnt[t] = c; rsum[t] = r;
     __syncthreads();
     // exclusive scan of the 1024 partial sums (Hillis-Steele, inclusive, then shifted by one)
@@ -152,10 +158,11 @@ __global__ __launch_bounds__(1024) void seg_offsets_k(SegParams P)
     if (t == 1023) P.off[P.S] = cnt[1023];
     long long a = cnt[t] - c; int b = rsum[t] - r;         // exclusive: the sums in front of this thread's slice
     for (int s = lo; s < hi; s++) {
-        b += P.rot[s];                       // window s is turned by the sum of the relative turns up to s
-        P.off[s] = a;
-        a += P.j1[s] - P.j0[s];
-        P.rot[s] = b & 3;
+        const int at = seg_slot(s, P.map_tiles);
+        b += P.rot[at];                      // window s is turned by the sum of the relative turns up to s
+        P.off[at] = a;
+        a += P.j1[at] - P.j0[at];
+        P.rot[at] = b & 3;
     }
 }
 
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(256) void seg_lead_copy_k(float2 *__restrict__ tile
 // window over the tiled filter output; sums in float64, in k order (the oracle adds in the same order).
 __global__ __launch_bounds__(512) void seg_phase_k(const float2 *__restrict__ tiles, int rows,
                                                    const int *__restrict__ lens, int S, int sps, int n_sym,
-                                                   double *__restrict__ mu0)
+                                                   double *__restrict__ mu0, const float2 *__restrict__ tile0)
 {
     // one wave per sampling phase (sps <= 8: the workgroup has sps waves), each adding its phase's
     // strobes in k order, 8 loads in flight; wave 0 then takes the first maximum over the phases
@@ -204,7 +211,8 @@ __global__ __launch_bounds__(512) void seg_phase_k(const float2 *__restrict__ ti
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, tile = blockIdx.x, w = tile * 64 + lane;
     const int len = w < S ? lens[w] : 0;
     const int ns = n_sym < len / sps ? n_sym : len / sps;
-    const float2 *base = tiles + (size_t)tile * rows * 64 + lane;
+    // (rows = rows between consecutive tiles' row 0; tile 0 may live elsewhere: SyncParams x_tile_rows / x_tile0)
+    const float2 *base = (tile == 0 && tile0 ? tile0 : tiles + (ptrdiff_t)tile * rows * 64) + lane;
     if (sps <= 8) {
         double acc = 0.0;
         for (int k0 = 0; k0 < ns; k0 += 8) {
@@ -337,26 +345,41 @@ hipError_t launch_lagrange_resample(const void *x, int c128, int len, const doub
 }
 
 hipError_t launch_seg_windows(int S, int64_t n_total, int64_t seg_len, int64_t lead, int64_t tail,
-                              int64_t *starts, int *lens, int *own_lo, int *own_hi, hipStream_t s)
+                              int64_t *starts, int *lens, int *own_lo, int *own_hi, hipStream_t s, int map_tiles)
 {
     hipLaunchKernelGGL(seg_windows_k, dim3((S + 255) / 256), dim3(256), 0, s, S, n_total, seg_len, lead, tail,
-                       starts, lens, own_lo, own_hi);
+                       starts, lens, own_lo, own_hi, map_tiles);
     return hipGetLastError();
 }
 
-// rows past a window's end, one 64-thread group per window (a few padding rows for most windows; the
-// first window has no warm-up and the last no tail, so theirs are `lead` / `tail` rows more)
-__global__ void seg_zero_past_k(float2 *__restrict__ tiles, int rows, const int *__restrict__ lens, int S)
+// Lane-major segment tiles: stream sample i is row i % seg_len of lane (i / seg_len) / nt of tile
+// (i / seg_len) % nt.  Row r < win_rows of lane l of `tile0` = window sample r of slot l (zero past the
+// window's end); row r < pad_rows behind the last tile = the sample that follows lane l's last segment.
+static __global__ __launch_bounds__(256) void seg_edge_tiles_k(float2 *tiles, int nt, int64_t seg_len, int64_t n_total,
+                                                        const int64_t *__restrict__ starts, const int *__restrict__ lens,
+                                                        float2 *__restrict__ tile0, int win_rows, int pad_rows)
 {
-    const int w = blockIdx.x;
-    if (w >= S) return;
-    float2 *col = tiles + (size_t)(w >> 6) * rows * 64 + (w & 63);
-    for (int r = lens[w] + threadIdx.x; r < rows; r += blockDim.x) col[(size_t)r * 64] = float2{0.f, 0.f};
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= win_rows + pad_rows) return;
+    int64_t i;
+    bool in;
+    if (r < win_rows) { i = starts[lane] + r; in = r < lens[lane]; }
+    else { i = ((int64_t)lane * nt + nt) * seg_len + (r - win_rows); in = true; }
+    float2 v = float2{0.f, 0.f};
+    if (in && i < n_total) {
+        const int64_t g = i / seg_len;
+        v = tiles[((size_t)(g % nt) * seg_len + (size_t)(i - g * seg_len)) * 64 + (size_t)(g / nt)];
+    }
+    if (r < win_rows) tile0[(size_t)r * 64 + lane] = v;
+    else tiles[((size_t)nt * seg_len + (size_t)(r - win_rows)) * 64 + lane] = v;
 }
 
-hipError_t launch_seg_zero_past(void *tiles, int rows, const int *lens, int S, hipStream_t s)
+hipError_t launch_seg_edge_tiles(void *tiles, int map_tiles, int64_t seg_len, int64_t n_total, const int64_t *starts,
+                                 const int *lens, void *tile0, int win_rows, int pad_rows, hipStream_t s)
 {
-    hipLaunchKernelGGL(seg_zero_past_k, dim3(S), dim3(64), 0, s, (float2 *)tiles, rows, lens, S);
+    hipLaunchKernelGGL(seg_edge_tiles_k, dim3((win_rows + pad_rows + 3) / 4), dim3(256), 0, s, (float2 *)tiles, map_tiles,
+                       seg_len, n_total, starts, lens, (float2 *)tile0, win_rows, pad_rows);
     return hipGetLastError();
 }
 
@@ -370,10 +393,10 @@ hipError_t launch_seg_lead_copy(void *tiles, int rows, const int64_t *starts, in
 }
 
 hipError_t launch_seg_phase(const void *tiles, int rows, const int *lens, int S, int sps, int n_sym, double *mu0,
-                            hipStream_t s)
+                            hipStream_t s, int x_tile_rows, const void *x_tile0)
 {
-    hipLaunchKernelGGL(seg_phase_k, dim3((S + 63) / 64), dim3(sps <= 8 ? 64 * sps : 64), 0, s, (const float2 *)tiles, rows,
-                       lens, S, sps, n_sym, mu0);
+    hipLaunchKernelGGL(seg_phase_k, dim3((S + 63) / 64), dim3(sps <= 8 ? 64 * sps : 64), 0, s, (const float2 *)tiles,
+                       x_tile_rows ? x_tile_rows : rows, lens, S, sps, n_sym, mu0, (const float2 *)x_tile0);
     return hipGetLastError();
 }
 

@@ -224,6 +224,15 @@ struct Tile {
     }
 };
 
+// row 0 of a tile's windows: tiles lie x_tile_rows rows apart (== in_rows for separate tiles; fewer when
+// consecutive tiles' windows overlap in one buffer, segment-parallel mode), tile 0 may live elsewhere
+template <typename IN>
+__device__ __forceinline__ const IN *tile_rows(const SyncParams &P, int tile)
+{
+    if (tile == 0 && P.x_tile0) return (const IN *)P.x_tile0;
+    return (const IN *)P.x + (ptrdiff_t)tile * P.x_tile_rows * 64;
+}
+
 template <typename IN>
 struct FetchFn {
     const Tile<IN> &t;
@@ -496,7 +505,7 @@ template <typename IN>
 __device__ __forceinline__ void tile_init(Tile<IN> &tl, const SyncParams &P, unsigned char *ring,
                                           int tile, int lane, double scale)
 {
-    tl.xt = (const IN *)P.x + (size_t)tile * P.in_rows * 64;
+    tl.xt = tile_rows<IN>(P, tile);
     tl.ring = ring;
     tl.lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)ring;
     tl.lane = lane; tl.R = P.ring_rows; tl.RM = P.ring_rows - 1; tl.in_rows = P.in_rows;
@@ -850,7 +859,7 @@ __global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
         }
     } else {
         // =================== FLL wave ===================
-        const IN *xt = (const IN *)P.x + (size_t)tile * P.in_rows * 64;
+        const IN *xt = tile_rows<IN>(P, tile);
         double freq = 0.0, integ = 0.0, i0 = 0.0;
         if (lane_ok) {
             if (P.fll_in) { freq = P.fll_in[2 * b]; integ = P.fll_in[2 * b + 1]; }
