@@ -352,7 +352,7 @@ def rank_main(args):
                                        "intermediate is not credited)",
                                "fir_ms": fir_ms, "sync_ms": kern_ms, "achieved": chain,
                                "frac": chain * 1e9 / HBM_PEAK, "bytes_per_sample": A_FULL,
-                               "fir_kernel": "fir_strip_kernel<c64> (+ fir_stream_kernel on the burst ends)",
+                               "fir_kernel": "fir_strip_kernel<c64> (+ fir_stats_finish)",
                                "fir_achieved": B * N * A_FIR / (fir_ms * 1e-3) / 1e9,
                                "fir_bytes_per_sample": A_FIR},
                      "decisions_only": None if lean_ms is None else

@@ -56,8 +56,11 @@ int dsp_set_option(dsp_ctx *ctx, const char *name, int64_t value); /* tuning kno
    "lds_pad", "split" (-1 auto / 0 one wave per tile / 1 two), "queue_block" (hand-off block, 0 auto),
    "prio_period" (rotate wave priorities every N DMA blocks, 0 off), "spare_wave" (two-wave kernel
    launched with idle waves so that two workgroups on a CU use four SIMDs: -1 auto = at two workgroups
-   per CU, 0 never, 1 one idle wave, 2 two idle waves chosen by a per-CU ticket), "lead_copy" (segment-parallel mode, a window's warm-up rows: 0 = stored
-   by the predecessor's filter workgroup, default; 1 = copied by a kernel after the filter; 2 = filtered again) */
+   per CU, 0 never, 1 one idle wave, 2 two idle waves chosen by a per-CU ticket), "lead_copy" (segment-parallel mode, a window's warm-up rows: 0 = default: the stream is filtered once
+   into lane-major segment tiles when it is a whole number of 64-segment tiles, else the warm-up rows are stored
+   by the predecessor's filter workgroup; 1 = copied by a kernel after the filter; 2 = filtered again),
+   "fir_stream" (matched filter of <= 41 taps on complex64 / int16 input: 2 = default, persistent fir_strip_kernel;
+   1 = fir_stream_kernel, one chunk per workgroup; 0 = round 1's tap-blocked fir_tile_kernel; same bits) */
 
 /* ---- device memory and timing (for *_dev pipelines and bench.py) ---------- */
 int dsp_malloc(dsp_ctx *ctx, size_t bytes, void **dptr);
