@@ -2,7 +2,7 @@
 """Diagnostic: per-wave start/end stamps of the split recurrence kernel (trace build only).
 
     make -C dsp_amd/csrc trace
-    DSP_HIP_LIB=dsp_amd/libdsp_hip_trace.so python tools/wave_timeline.py [bursts]
+    DSP_HIP_LIB=dsp_amd/libdsp_hip_trace.so python tools/wave_timeline.py [bursts] [--check]
 
 Prints how the tiles were spread over XCDs / CUs / SIMDs and how long the waves lived,
 which is what decides whether a launch is balanced.  Never used by the product path.
@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dsp_amd                                               # noqa: E402
 from dsp_amd.pipeline import BurstPipeline                   # noqa: E402
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 65536
 ctx = dsp_amd.Context(0)
 pipe = BurstPipeline(ctx, B, 2048, 4)
 pipe.generate()
@@ -64,6 +64,16 @@ print(f"G and F wave of a tile on the same SIMD: {same * 100:.1f}%")
 sc = collections.Counter((cuid * 4 + simd[:, 0]).tolist())
 sc.update((cuid * 4 + simd[:, 1]).tolist())
 print("waves per SIMD histogram:", sorted(collections.Counter(sc.values()).items()))
+if "--check" in sys.argv:
+    # self-check of the idle-wave launches (DESIGN.md 3.1 finding 5): with at most two tiles on a CU
+    # (four live waves) no SIMD may carry two of them
+    if max(cnt.values()) <= 2:
+        worst = max(sc.values())
+        print("SIMD placement check:", "ok" if worst == 1 else f"FAILED ({worst} live waves on one SIMD)")
+        if worst != 1:
+            sys.exit(1)
+    else:
+        print("SIMD placement check: skipped (more than two tiles per CU)")
 # lifetime as a function of how many tiles shared the CU
 for n in sorted(set(cnt.values())):
     m = np.array([cnt[c] == n for c in cuid.tolist()])
