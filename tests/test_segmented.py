@@ -319,3 +319,49 @@ def test_gpu_shared_warmup_rows_bit_identical(oracle, ctx, n_keep):
     assert np.mean(outs[0]["dec"] == ref["dec"]) > 0.9999
     n = min(ref["n"], q.size)
     assert best_rotation_match(outs[0]["dec"][500:n], q[500:n]) > 0.999
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nseg,seg_len,warm,kind,acquire", [
+    (64, 4096, 1024, "i16", True),          # one tile: every window is an edge-tile window
+    (128, 2048, 512, "c64", True),          # warm-up == seg_len / sps: the longest lead the segment tiles take
+    (128, 2048, 0, "i16", True),            # no warm-up at all
+    (192, 2048, 256, "c64", False),         # fixed start value instead of the energy rule
+    (256, 1024, 128, "i16", True),
+])
+def test_gpu_segment_tiles_match_window_tiles(oracle, ctx, nseg, seg_len, warm, kind, acquire):
+    """Whole tiles of whole segments with the matched filter: the stream is filtered once into lane-major
+    segment tiles and the windows are row ranges of that buffer.  Every output --
+    decisions, mu, frequency, shares, rotations -- has the bits of the pass over the overlapping windows
+    (lead_copy 2 filters every window on its own), for int16 and complex64 input; decisions follow the
+    oracle's segmented definition as closely as that pass does."""
+    import dsp_amd
+    n = nseg * seg_len
+    q, x, h = make_stream(n // SPS + 64, seed=31 + nseg)
+    x = x[:n]
+    if kind == "i16":
+        pk = np.max(np.abs(np.concatenate((x.real, x.imag))))
+        w = np.empty(2 * x.size, np.int16)
+        w[0::2] = np.round(x.real / pk * 20000)
+        w[1::2] = np.round(x.imag / pk * 20000)
+        xin, xc = w, oracle.read_iq_int16_words(w, True)
+    else:
+        xin = x.astype(np.complex64)
+        xc = xin
+    outs = []
+    try:
+        for mode in (2, 0):
+            ctx.set_option("lead_copy", mode)
+            outs.append(dsp_amd.sync_capture_segmented(xin, SPS, 0.007, 0.0, 0.003, 1, taps=h, seg_len=seg_len,
+                                                       warmup=warm, acquire=acquire, ctx=ctx))
+    finally:
+        ctx.set_option("lead_copy", 0)
+    a, b = outs
+    assert a["seg_info"].shape[0] == nseg and a["n"] == b["n"]
+    for k in ("dec", "mu", "freq", "seg_info"):
+        assert np.array_equal(a[k], b[k]), k
+    yf = oracle.convolve_same(xc, h)
+    ref = oracle.sync_capture_segmented(yf.astype(np.complex64), SPS, 0.007, 0.0, 0.003, 1.0, seg_len=seg_len,
+                                        warmup=warm, scale=1.0 / oracle.np_std(yf), acquire=acquire)
+    assert b["n"] == ref["n"]
+    assert np.mean(b["dec"] == ref["dec"]) > 0.9999
