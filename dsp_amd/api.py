@@ -21,6 +21,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import math
+
 import numpy as np
 
 from . import _lib
@@ -341,7 +343,11 @@ def auto_seg_len(n, sps, warmup):
     paying the filter for the overlap.  DESIGN.md 3.5 has the sweep behind these numbers."""
     sps = int(sps)
     lead = int(warmup) * sps
-    seg = (int(n) // (512 * 64)) // sps * sps
+    # rounded UP to a multiple of sps and of four samples: at most 512 tiles, all of them full (the last
+    # segment is the short one) -- whole tiles of segments are filtered once into segment tiles, and one
+    # tile more than 512 would be a third workgroup on some CUs
+    q = sps * 4 // math.gcd(sps, 4)
+    seg = -(-int(n) // (512 * 64 * q)) * q
     if seg >= lead:
         return int(max(min(seg, max(2 * lead, 8192 * sps)), 1024 * sps))
     seg = (int(n) // (128 * 64)) // sps * sps

@@ -1383,9 +1383,10 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
     ScratchRef d_starts, d_lens, d_nout, d_status, d_j0, d_j1, d_rot, d_pl, d_off;
     ScratchRef d_tiles, d_mu, d_pos, d_dec, d_freq;
     Bump small;
-    small.cap = (size_t)64 * 1024 + (size_t)S * 96;
+    const int Sa = (int)ntiles * 64;                        // slots: the per-window arrays hold whole tiles
+    small.cap = (size_t)64 * 1024 + (size_t)Sa * 96;
     HIP_TRY(ctx_scratch(c, 5, small.cap, (void **)&small.base));
-    d_starts.p = small.take((size_t)S * 8); d_lens.p = small.take((size_t)S * 4);
+    d_starts.p = small.take((size_t)Sa * 8); d_lens.p = small.take((size_t)Sa * 4);
     // window tiles [ntiles][rows][64], or (by_segment below) lane-major segment tiles [ntiles][seg][64] + the
     // rows behind the last one + tile 0's windows: the buffer serves either
     const int64_t pad_rows = rows - lead - seg > 0 ? rows - lead - seg : 0;
@@ -1399,17 +1400,17 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
     HIP_TRY(ctx_scratch(c, 3, (size_t)ntiles * out_rows * 64, &d_dec.p));
     if (a->freq) HIP_TRY(ctx_scratch(c, 4, (size_t)ntiles * out_rows * 64 * 4, &d_freq.p));
     // j0 | j1 | rot | n_out lie back to back: one copy brings seg_info home
-    d_j0.p = small.take((size_t)S * 16);
-    d_j1.p = d_j0.as<int>() + S; d_rot.p = d_j0.as<int>() + 2 * (size_t)S; d_nout.p = d_j0.as<int>() + 3 * (size_t)S;
-    d_status.p = small.take((size_t)S * 4);
-    d_pl.p = small.take((size_t)S * 8); d_off.p = small.take((size_t)(S + 1) * 8);
+    d_j0.p = small.take((size_t)Sa * 16);
+    d_j1.p = d_j0.as<int>() + Sa; d_rot.p = d_j0.as<int>() + 2 * (size_t)Sa; d_nout.p = d_j0.as<int>() + 3 * (size_t)Sa;
+    d_status.p = small.take((size_t)Sa * 4);
+    d_pl.p = small.take((size_t)Sa * 8); d_off.p = small.take((size_t)(Sa + 1) * 8);
     // ---- windows -> tiles (optionally through the matched filter) ------------------------
     ScratchRef d_peak, d_c64, d_ws, d_inv, d_lo, d_hi, d_part, d_mu0;
     d_peak.p = small.take(16);
-    d_lo.p = small.take((size_t)S * 4); d_hi.p = small.take((size_t)S * 4);
-    d_inv.p = small.take((size_t)S * 8);
+    d_lo.p = small.take((size_t)Sa * 4); d_hi.p = small.take((size_t)Sa * 4);
+    d_inv.p = small.take((size_t)Sa * 8);
     d_part.p = small.take((size_t)1024 * 32);
-    d_mu0.p = small.take((size_t)S * 8);
+    d_mu0.p = small.take((size_t)Sa * 8);
     if (small.off > small.cap) return fail(DSP_E_NOMEM, "capture: scratch block too small");
     // the filter pass writes every row of every lane (zeros past a window's end and in the idle lanes
     // of the last tile: its chunks cover ceil(Nw / CH) * CH >= rows); only the copy path needs clearing
@@ -1427,15 +1428,16 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
     FirParams Q;
     memset(&Q, 0, sizeof(Q));
     bool by_segment = false;
-    if (a->h && c->fir_stream == 2 && c->lead_copy == 0 && S % 64 == 0 && n == (int64_t)S * seg && lead <= seg &&
+    if (a->h && c->fir_stream == 2 && c->lead_copy == 0 && S >= 64 && lead <= seg &&
         tail <= seg && seg < (1 << 30) && fir_plan(a->in_kind, a->n_taps, (int)seg, Q, true) && Q.stream) {
         Q.stream_mode = 1; Q.strip_ok = 1; Q.n_cu = c->n_cu;
-        Q.src = a->x; Q.n_total = n; Q.ld = seg; Q.len_all = (int)seg; Q.B = S;
+        Q.src = a->x; Q.n_total = n; Q.ld = seg; Q.len_all = (int)seg; Q.B = Sa;   // whole tiles: the segments behind the stream's end are empty
         Q.h = a->h; Q.M = a->n_taps; Q.start = (a->n_taps - 1) / 2; Q.h_pad = c->fir_taps;
         Q.in_scale = in_scale; Q.dst = d_tiles.p; Q.rows = (int)seg;
         by_segment = fir_stream_mode_plan(Q, a->in_kind);
     }
     const int map_tiles = by_segment ? (int)ntiles : 0;
+    const int n_slots = by_segment ? Sa : S;                // windows the recurrence kernel sees (the empty ones have length 0)
     // the recurrence kernel's view of the windows: rows of tile t start x_tile_rows * t rows after win_x
     const void *win_x = by_segment ? (const void *)((const char *)d_tiles.p - (ptrdiff_t)lead * 64 * 8) : d_tiles.p;
     void *win_tile0 = by_segment ? (void *)((char *)d_tiles.p + ((size_t)ntiles * seg + pad_rows) * 64 * 8) : nullptr;
@@ -1448,9 +1450,26 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
         // over each window's own samples only (the windows' shares partition the stream), merged
         // into the np.std of the whole filtered stream; 1/std is applied by the recurrence kernel
         if (by_segment) {
-            HIP_TRY(ctx_scratch(c, 6, (size_t)S * (Q.nchunk + 8) * 32, &d_ws.p));
+            // a last segment cut short by the stream's end is left out of the strips' statistics and
+            // counted by a pass over the last window alone (statistics only, its own samples)
+            FirParams W;
+            memset(&W, 0, sizeof(W));
+            const bool cut = n < (int64_t)S * seg;
+            if (cut && !fir_plan(a->in_kind, a->n_taps, (int)Nw, W, true))
+                return fail(DSP_E_ARG, "capture: %d taps are too many for the LDS-tiled filter", a->n_taps);
+            HIP_TRY(ctx_scratch(c, 6, ((size_t)Sa * (Q.nchunk + 8) + (cut ? W.nchunk : 0)) * 32, &d_ws.p));
             Q.stats = d_ws.as<double>();
             HIP_TRY(launch_fir_tile(Q, a->in_kind, st));
+            if (cut) {
+                W.h_pad = c->fir_taps; W.src = a->x; W.n_total = n; W.len_all = (int)Nw; W.B = 1;
+                const int last = seg_slot(S - 1, map_tiles);
+                W.starts = d_starts.as<int64_t>() + last; W.lens = d_lens.as<int>() + last;
+                W.stat_lo = d_lo.as<int>() + last; W.stat_hi = d_hi.as<int>() + last;
+                W.h = a->h; W.M = a->n_taps; W.start = (a->n_taps - 1) / 2; W.in_scale = in_scale;
+                W.dst = nullptr; W.rows = (int)rows; W.stats = Q.stats + (size_t)Sa * Q.nrec * 4;
+                HIP_TRY(launch_fir_tile(W, a->in_kind, st));
+                Q.nrec_extra = W.nrec;
+            }
             HIP_TRY(launch_seg_edge_tiles(d_tiles.p, map_tiles, seg, n, d_starts.as<int64_t>(), d_lens.as<int>(), win_tile0,
                                           (int)rows, (int)pad_rows, st));
         } else {
@@ -1473,7 +1492,7 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
             if (share_lead && c->lead_copy == 1)                      // ... or a copy kernel does afterwards
                 HIP_TRY(launch_seg_lead_copy(d_tiles.p, (int)rows, d_starts.as<int64_t>(), S, (int)lead, st));
         }
-        HIP_TRY(launch_fir_stats_global(Q.stats, (int64_t)S * Q.nrec, S, nullptr, d_inv.as<double>(),
+        HIP_TRY(launch_fir_stats_global(Q.stats, (int64_t)(by_segment ? Sa : S) * Q.nrec + Q.nrec_extra, n_slots, nullptr, d_inv.as<double>(),
                                         d_part.as<double>(), 1024, st));
         d_scale = d_inv.as<double>();
     } else {
@@ -1484,7 +1503,7 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
 
     // ---- initial timing phase per window (strobe energy), unless the caller fixes mu0 ------------
     if (a->acquire) {
-        HIP_TRY(launch_seg_phase(win_x, (int)rows, d_lens.as<int>(), S, sps, DSP_ACQUIRE_SYMBOLS,
+        HIP_TRY(launch_seg_phase(win_x, (int)rows, d_lens.as<int>(), n_slots, sps, DSP_ACQUIRE_SYMBOLS,
                                  d_mu0.as<double>(), st, win_stride, win_tile0));
     }
 
@@ -1492,7 +1511,7 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
     dsp_sync_args sa;
     memset(&sa, 0, sizeof(sa));
     sa.mu0_per = a->acquire ? d_mu0.as<double>() : nullptr;
-    sa.x = win_x; sa.dtype = DSP_C64; sa.variant = DSP_GARDNER2; sa.B = S; sa.N = Nw; sa.in_rows = rows;
+    sa.x = win_x; sa.dtype = DSP_C64; sa.variant = DSP_GARDNER2; sa.B = n_slots; sa.N = Nw; sa.in_rows = rows;
     sa.lens = d_lens.as<int32_t>(); sa.scale = d_scale; sa.sps = sps; sa.alpha = a->alpha; sa.mu0 = a->mu0; sa.do_fll = 1;
     sa.Bn = a->Bn; sa.y = a->y; sa.mu = a->mu ? d_mu.p : nullptr; sa.pos = d_pos.p; sa.dec = d_dec.as<uint8_t>(); sa.freq = a->freq ? d_freq.p : nullptr;
     sa.out_rows = out_rows; sa.n_out = d_nout.as<int32_t>(); sa.status = d_status.as<int32_t>();
@@ -1504,7 +1523,7 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
     // ---- stitch ----------------------------------------------------------------------------
     SegParams G;
     memset(&G, 0, sizeof(G));
-    G.S = S; G.sps = sps; G.out_rows = (int)out_rows; G.n_total = n; G.seg_len = seg; G.map_tiles = map_tiles;
+    G.S = S; G.sps = sps; G.out_rows = (int)out_rows; G.n_total = n; G.seg_len = seg; G.map_tiles = map_tiles; G.n_slots = n_slots;
     G.starts = d_starts.as<int64_t>(); G.n_out = d_nout.as<int>(); G.mu = a->mu ? d_mu.p : nullptr; G.pos = d_pos.p; G.dec = d_dec.as<uint8_t>();
     G.freq = a->freq ? d_freq.p : nullptr;
     G.j0 = d_j0.as<int>(); G.j1 = d_j1.as<int>(); G.p_last = d_pl.as<double>(); G.rot = d_rot.as<int>();
@@ -1514,15 +1533,15 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
     HIP_TRY(launch_seg_stitch(G, vote, st));
     HIP_TRY(launch_seg_gather(G, a->dec, a->mu, a->freq, a->capacity, st));
     int64_t total = 0;
-    HIP_TRY(hipMemcpyAsync(&total, d_off.as<int64_t>() + S, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&total, d_off.as<int64_t>() + n_slots, 8, hipMemcpyDeviceToHost, st));
     if (a->seg_info) {
-        std::vector<int32_t> info((size_t)S * 4);            // [j0 | j1 | rot | n_out]
-        HIP_TRY(hipMemcpyAsync(info.data(), d_j0.p, (size_t)S * 16, hipMemcpyDeviceToHost, st));
+        std::vector<int32_t> info((size_t)Sa * 4);           // [j0 | j1 | rot | n_out], Sa slots each
+        HIP_TRY(hipMemcpyAsync(info.data(), d_j0.p, (size_t)Sa * 16, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         for (size_t s = 0; s < (size_t)S; s++) {
             const size_t at = (size_t)seg_slot((int)s, map_tiles);           // the device arrays are in slot order
-            a->seg_info[4 * s] = info[at]; a->seg_info[4 * s + 1] = info[S + at];
-            a->seg_info[4 * s + 2] = info[2 * (size_t)S + at]; a->seg_info[4 * s + 3] = info[3 * (size_t)S + at];
+            a->seg_info[4 * s] = info[at]; a->seg_info[4 * s + 1] = info[Sa + at];
+            a->seg_info[4 * s + 2] = info[2 * (size_t)Sa + at]; a->seg_info[4 * s + 3] = info[3 * (size_t)Sa + at];
         }
     }
     HIP_TRY(hipStreamSynchronize(st));

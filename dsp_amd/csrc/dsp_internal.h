@@ -95,6 +95,7 @@ struct FirParams {
     int waves;                // waves per workgroup: 0 = auto (8 where the chunk divides), 4 = always 4
     int stream;               // set by fir_plan: 1 = fir_stream_kernel (<= 41 taps, float32 staging)
     int strip_ok;             // in: launch_fir_tile may use the persistent fir_strip_kernel
+    int nrec_extra;           // caller's note: records appended behind the B * nrec of this pass (capture mode)
     int stream_mode;          // in: the bursts are the consecutive segments of one stream of n_total samples,
                               //     lane l of tile t = segment l * ntiles + t, rows == len_all == ld
                               //     (fir_strip_kernel STREAM; cleared by fir_stream_mode_plan if it cannot serve)
@@ -156,11 +157,18 @@ struct SegParams {
     // lane s / map_tiles of tile s % map_tiles, so that a lane's windows in consecutive tiles are
     // consecutive segments of the stream.
     int map_tiles;
+    int n_slots;              // slots the arrays hold (>= S; 64 * map_tiles when mapped: the slots behind the
+                              // last window are empty windows, lens == 0); off[n_slots] receives the total
 };
 static inline __host__ __device__ int seg_slot(int s, int map_tiles)
 {
     return map_tiles > 0 ? (s % map_tiles) * 64 + s / map_tiles : s;
 }
+static inline __host__ __device__ int seg_of_slot(int slot, int map_tiles)
+{
+    return map_tiles > 0 ? (slot & 63) * map_tiles + (slot >> 6) : slot;
+}
+// (map_tiles > 0: the arrays hold 64 * map_tiles slots; those of the windows >= S get length 0)
 hipError_t launch_seg_windows(int S, int64_t n_total, int64_t seg_len, int64_t lead, int64_t tail,
                               int64_t *starts, int *lens, int *own_lo, int *own_hi, hipStream_t s, int map_tiles = 0);
 // Lane-major segment tiles (fir_strip_kernel STREAM: [map_tiles][seg_len][64] at `tiles`): the windows of

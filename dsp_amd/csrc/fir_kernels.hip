@@ -613,9 +613,9 @@ __global__ __launch_bounds__(512, 4) void fir_strip_kernel(FirParams P)
                 if (idx < RQ * HALO) myrows[q * stride + i] = keep[j];
             }
             if (lane < LPR) {
-                // nothing to mask: the new samples lie inside the burst (inside the stream: all but the
-                // last tile's rows can never reach its end)
-                const bool whole = STREAM ? (tile + 1 < ntiles || (int64_t)(P.B - 1) * P.ld + cn * CH + P.start + CH <= P.n_total)
+                // nothing to mask: the new samples lie inside the burst (inside the stream: row 63 holds
+                // the tile's last segment, 63 * ntiles + tile; if its samples are inside, every row's are)
+                const bool whole = STREAM ? ((int64_t)(63 * ntiles + tile) * P.ld + cn * CH + P.start + CH <= P.n_total)
                                           : (cn * CH + P.start + CH <= len);
                 if (whole) {
 #pragma unroll
@@ -639,8 +639,11 @@ __global__ __launch_bounds__(512, 4) void fir_strip_kernel(FirParams P)
         __syncthreads();
     }
     if (P.stats) {
-        // this lane's (n, mean, M2) over the strip as record strip * NW + w of its burst
-        const double n = (double)cnt;
+        // this lane's (n, mean, M2) over the strip as record strip * NW + w of its burst.  STREAM: a last
+        // segment that the stream's end cuts short is left out here (its outputs past the end are the
+        // filter's tail over zeros); the caller adds its statistics with a pass of its own
+        const bool cut = STREAM && (int64_t)(b + 1) * P.ld > P.n_total;
+        const double n = cut ? 0.0 : (double)cnt;
         const double mr = cnt ? s_re / n : 0.0, mi = cnt ? s_im / n : 0.0;    // mean of (y - c)
         double m2 = cnt ? s_sq - n * (mr * mr + mi * mi) : 0.0;
         if (m2 < 0.0) m2 = 0.0;
@@ -985,7 +988,10 @@ static void fir_plan_strips(FirParams &P, int in_kind)
     const int esz = in_kind == DSP_IN_I16 ? 4 : 8;
     if (P.ld % spl || (P.start - (FIR_MT - 1)) % spl || ((uintptr_t)P.src & 15) || (P.ld * esz) % 16) return;
     if (P.len_all % spl || P.rows < P.len_all || P.start < 0) return;   // the bursts' ends fall on 16-byte pieces
-    if (P.stream_mode && (P.B % 64 || P.ld != P.len_all || P.n_total != (int64_t)P.B * P.ld || !P.dst || P.scale ||
+    // (the stream may end anywhere inside the B segments, on a 16-byte piece: a cut segment and empty ones
+    //  behind it are zeros to the filter and left out of its statistics)
+    if (P.stream_mode && (P.B % 64 || P.ld != P.len_all || P.n_total > (int64_t)P.B * P.ld || P.n_total <= 0 ||
+                          P.n_total % spl || !P.dst || P.scale ||
                           P.rows != P.len_all)) { P.stream_mode = 0; return; }
     const int c0 = 0, c1 = P.nchunk;                                     // the strips cover every chunk
     const int nint = c1 - c0, full = P.B / 64;

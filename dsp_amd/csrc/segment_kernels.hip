@@ -40,8 +40,14 @@ __global__ void seg_windows_k(int S, int64_t n_total, int64_t seg_len, int64_t l
                               int *__restrict__ own_lo, int *__restrict__ own_hi, int map_tiles)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
+    if (s >= (map_tiles > 0 ? 64 * map_tiles : S)) return;
     const int at = seg_slot(s, map_tiles);
+    if (s >= S) {                                   // an empty window behind the stream's end
+        starts[at] = 0; lens[at] = 0;
+        if (own_lo) own_lo[at] = 0;
+        if (own_hi) own_hi[at] = 0;
+        return;
+    }
     int64_t st = (int64_t)s * seg_len - lead;
     if (st < 0) st = 0;
     int64_t en = (int64_t)(s + 1) * seg_len + tail;
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(1024) void seg_offsets_k(SegParams P)
         cnt[t] += c1; rsum[t] += r1;
         __syncthreads();
     }
-    if (t == 1023) P.off[P.S] = cnt[1023];
+    if (t == 1023) P.off[P.n_slots] = cnt[1023];
     long long a = cnt[t] - c; int b = rsum[t] - r;         // exclusive: the sums in front of this thread's slice
     for (int s = lo; s < hi; s++) {
         const int at = seg_slot(s, P.map_tiles);
@@ -261,7 +267,8 @@ __global__ __launch_bounds__(256) void seg_gather_k(SegParams P, uint8_t *__rest
     {
         // rows no window of this tile keeps (the warm-up rows, mostly): nothing to read or write
         const int sw = tile * 64 + lane;
-        int lo = sw < P.S ? P.j0[sw] : 0x7fffffff, hi = sw < P.S ? P.j1[sw] : 0;
+        const bool real = sw < P.n_slots && seg_of_slot(sw, P.map_tiles) < P.S;
+        int lo = real ? P.j0[sw] : 0x7fffffff, hi = real ? P.j1[sw] : 0;
         for (int d = 32; d >= 1; d >>= 1) {
             const int ol = __shfl_xor(lo, d), oh = __shfl_xor(hi, d);
             lo = ol < lo ? ol : lo; hi = oh > hi ? oh : hi;
@@ -293,8 +300,8 @@ __global__ __launch_bounds__(256) void seg_gather_k(SegParams P, uint8_t *__rest
     }
     __syncthreads();
     for (int i = 0; i < 16; i++) {
-        const int bb = w * 16 + i, s = tile * 64 + bb;
-        if (s >= P.S) continue;
+        const int bb = w * 16 + i, s = tile * 64 + bb;            // a slot
+        if (s >= P.n_slots || seg_of_slot(s, P.map_tiles) >= P.S) continue;
         const int row = r0 + lane;
         const int j0 = P.j0[s], j1 = P.j1[s];
         if (row < j0 || row >= j1) continue;
@@ -347,7 +354,8 @@ hipError_t launch_lagrange_resample(const void *x, int c128, int len, const doub
 hipError_t launch_seg_windows(int S, int64_t n_total, int64_t seg_len, int64_t lead, int64_t tail,
                               int64_t *starts, int *lens, int *own_lo, int *own_hi, hipStream_t s, int map_tiles)
 {
-    hipLaunchKernelGGL(seg_windows_k, dim3((S + 255) / 256), dim3(256), 0, s, S, n_total, seg_len, lead, tail,
+    const int n = map_tiles > 0 ? 64 * map_tiles : S;
+    hipLaunchKernelGGL(seg_windows_k, dim3((n + 255) / 256), dim3(256), 0, s, S, n_total, seg_len, lead, tail,
                        starts, lens, own_lo, own_hi, map_tiles);
     return hipGetLastError();
 }
@@ -412,7 +420,7 @@ hipError_t launch_seg_stitch(const SegParams &P, int overlap_vote, hipStream_t s
 hipError_t launch_seg_gather(const SegParams &P, uint8_t *dec_out, float *mu_out, float *freq_out,
                              int64_t capacity, hipStream_t s)
 {
-    dim3 grid((P.out_rows + 63) / 64, (P.S + 63) / 64);
+    dim3 grid((P.out_rows + 63) / 64, (P.n_slots + 63) / 64);
     hipLaunchKernelGGL(seg_gather_k, grid, dim3(256), 0, s, P, dec_out, mu_out, freq_out, capacity);
     return hipGetLastError();
 }

@@ -322,21 +322,25 @@ def test_gpu_shared_warmup_rows_bit_identical(oracle, ctx, n_keep):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nseg,seg_len,warm,kind,acquire", [
-    (64, 4096, 1024, "i16", True),          # one tile: every window is an edge-tile window
-    (128, 2048, 512, "c64", True),          # warm-up == seg_len / sps: the longest lead the segment tiles take
-    (128, 2048, 0, "i16", True),            # no warm-up at all
-    (192, 2048, 256, "c64", False),         # fixed start value instead of the energy rule
-    (256, 1024, 128, "i16", True),
+@pytest.mark.parametrize("nseg,seg_len,warm,kind,acquire,trim", [
+    (64, 4096, 1024, "i16", True, 0),       # one tile: every window is an edge-tile window
+    (128, 2048, 512, "c64", True, 0),       # warm-up == seg_len / sps: the longest lead the segment tiles take
+    (128, 2048, 0, "i16", True, 0),         # no warm-up at all
+    (192, 2048, 256, "c64", False, 0),      # fixed start value instead of the energy rule
+    (256, 1024, 128, "i16", True, 0),
+    (128, 2048, 256, "i16", True, 1000),    # the stream ends inside its last segment
+    (130, 2048, 256, "i16", True, 0),       # 62 empty segments behind the stream's end (lane-major: lanes 43.. of tile 1, ...)
+    (150, 2048, 512, "c64", True, 1234),    # both
+    (70, 4096, 1024, "i16", True, 1332),
 ])
-def test_gpu_segment_tiles_match_window_tiles(oracle, ctx, nseg, seg_len, warm, kind, acquire):
+def test_gpu_segment_tiles_match_window_tiles(oracle, ctx, nseg, seg_len, warm, kind, acquire, trim):
     """Whole tiles of whole segments with the matched filter: the stream is filtered once into lane-major
     segment tiles and the windows are row ranges of that buffer.  Every output --
     decisions, mu, frequency, shares, rotations -- has the bits of the pass over the overlapping windows
     (lead_copy 2 filters every window on its own), for int16 and complex64 input; decisions follow the
     oracle's segmented definition as closely as that pass does."""
     import dsp_amd
-    n = nseg * seg_len
+    n = nseg * seg_len - trim
     q, x, h = make_stream(n // SPS + 64, seed=31 + nseg)
     x = x[:n]
     if kind == "i16":

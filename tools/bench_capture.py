@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Config 5 of BASELINE.json: one continuous int16 IQ capture, segment-parallel receiver.
 
-    python tools/bench_capture.py [log2_samples=28] [seg_len=auto] [warmup=4096]
+    python tools/bench_capture.py [log2_samples=28] [seg_len=auto] [warmup=4096] [trim=0]
+
+(trim: the capture is 2^log2_samples - trim samples long, for sizes that are not whole segments)
 
 Generates the capture on the device, runs the whole segmented receiver (peak, RRC + std of the
 whole stream, windows, Gardner + FLL, stitching), checks the decisions against the transmitted
@@ -49,7 +51,8 @@ def main():
     lg = int(sys.argv[1]) if len(sys.argv) > 1 else 28
     seg_len = int(sys.argv[2]) if len(sys.argv) > 2 and int(sys.argv[2]) > 0 else None
     warmup = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
-    n, sps = 1 << lg, 4
+    trim = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    n, sps = (1 << lg) - trim, 4
     tau0, drift = 0.3, 2.0e-8
     ctx = dsp_amd.Context(0)
     for kv in os.environ.get("DSP_CAPTURE_OPTS", "").split(","):      # e.g. ring_rows=256,queue_block=32
@@ -69,7 +72,7 @@ def main():
     expect = int(round(n * (1.0 + drift) / sps))       # a drifting symbol clock changes the symbol count
     assert abs(nsym - expect) <= 4, (nsym, expect)
     assert rate > 0.999, rate
-    line = {"workload": f"one int16 IQ capture of 2^{lg} samples (4 sps QPSK, RRC 0.35, CFO 1.5e-4, drifting timing, "
+    line = {"workload": f"one int16 IQ capture of {'2^%d' % lg if not trim else n} samples (4 sps QPSK, RRC 0.35, CFO 1.5e-4, drifting timing, "
                         f"Es/N0 20 dB), segment-parallel: seg_len {pipe.seg_len}, warm-up {warmup} symbols",
             "segments": pipe.S, "symbols": nsym, "ms": ms, "wall_ms": wall * 1e3,
             "Msamples_per_s": n / ms / 1e3, "symbol_match_rate": rate,

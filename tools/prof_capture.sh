@@ -1,10 +1,10 @@
 # rocprofv3 kernel stats of tools/bench_capture.py on the GPU box:
-#   bash tools/prof_capture.sh <log2_samples> <seg_len, 0 = auto> <tag>
+#   bash tools/prof_capture.sh <log2_samples> <seg_len, 0 = auto> <tag> [warm-up symbols] [trim samples]
 # leaves gpurun_out/cap/kstats_<tag>.csv, gpurun_out/cap/kstats_<tag>.txt (the table kept under profiles/)
 set -e
 R=$PWD; mkdir -p $R/gpurun_out/cap
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --stats -d /tmp/pc_$3 -o p --output-format csv -- python3 $R/tools/bench_capture.py $1 $2 > $R/gpurun_out/cap/prof_$3.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d /tmp/pc_$3 -o p --output-format csv -- python3 $R/tools/bench_capture.py $1 $2 ${4:-4096} ${5:-0} > $R/gpurun_out/cap/prof_$3.log 2>&1
 f=$(find /tmp/pc_$3 -name '*kernel_stats.csv' | head -1)
 cp $f $R/gpurun_out/cap/kstats_$3.csv
 python3 - $R/gpurun_out/cap/kstats_$3.csv $R/gpurun_out/cap/prof_$3.log > $R/gpurun_out/cap/kstats_$3.txt <<'PY'
