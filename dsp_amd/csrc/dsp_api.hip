@@ -25,6 +25,7 @@ struct dsp_ctx {
     int lead_copy;      // segment-parallel mode, warm-up rows: 0 = the filter's second store, 1 = seg_lead_copy_k, 2 = filtered per window
     int spare_wave;     // split kernel, idle waves for SIMD balance: -1 auto, 0 never, 1 three waves, 2 four waves + CU tickets
     unsigned *cu_tickets;   // [4096] per-CU workgroup counters for the four-wave launch
+    unsigned *place;        // diagnostic (option "place_ptr"): caller's device buffer [tiles][2] for the live waves' HW_ID
     int fir_stream;     // matched filter of <= 41 taps: 2 = persistent fir_strip_kernel where eligible (default),
                         // 1 = fir_stream_kernel, 0 = the tap-blocked kernel
     double *fir_taps;   // [64] the stream kernel's zero-padded taps
@@ -153,7 +154,7 @@ int dsp_create(int device_id, dsp_ctx **out)
     c->trace = nullptr;
     c->trace_stamps = 0;
 #endif
-    c->stream = nullptr; c->ev0 = nullptr; c->ev1 = nullptr; c->cu_tickets = nullptr;
+    c->stream = nullptr; c->ev0 = nullptr; c->ev1 = nullptr; c->cu_tickets = nullptr; c->place = nullptr;
     hipDeviceProp_t prop;
     hipError_t e = hipGetDeviceProperties(&prop, device_id);
     if (e == hipSuccess) {
@@ -259,6 +260,8 @@ int dsp_set_option(dsp_ctx *c, const char *name, int64_t value)
     } else if (!strcmp(name, "trace_stamps")) {
         c->trace_stamps = (int)value;
 #endif
+    } else if (!strcmp(name, "place_ptr")) {     // diagnostic: device buffer of 2 x tiles unsigned, 0 = off
+        c->place = (unsigned *)(uintptr_t)value;
     } else if (!strcmp(name, "fir_stream")) {
         if (value < 0 || value > 2) return fail(DSP_E_ARG, "fir_stream must be 0, 1 or 2");
         c->fir_stream = (int)value;
@@ -537,6 +540,7 @@ static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, c
         // CU, 3 % slower at three or four, and at eight the spare waves cost occupancy
         P.spare_wave = c->spare_wave >= 0 ? c->spare_wave : (per_cu == 2 ? 2 : 0);
         P.cu_tickets = c->cu_tickets;
+        P.place = c->place;
         lds += (size_t)2 * TQ * 64 * 17 + 16 + 32;       // + the four-wave launch's five selection words
     }
     if (c->lds_pad >= 0) lds += (size_t)c->lds_pad;

@@ -735,6 +735,8 @@ __global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
         second = __builtin_amdgcn_readfirstlane(second);
         if (wv != first && wv != second) return;
         role = wv == first ? 0 : 1;
+        // self-check of the placement (dsp_set_option("place_ptr"), tests/test_gpu_fullsize.py)
+        if (P.place && lane == 0) P.place[tile * 2 + role] = 0x80000000u | ((xcc & 15u) << 16) | (hw & 0xffffu);
     }
     const unsigned slot = wave_slot();
     int prio_n = P.prio_period, prio_c = 1, prio_ph = 0;

@@ -59,6 +59,8 @@ int dsp_set_option(dsp_ctx *ctx, const char *name, int64_t value); /* tuning kno
    per CU, 0 never, 1 one idle wave, 2 two idle waves chosen by a per-CU ticket), "lead_copy" (segment-parallel mode, a window's warm-up rows: 0 = default: the stream is filtered once
    into lane-major segment tiles when it is a whole number of 64-segment tiles, else the warm-up rows are stored
    by the predecessor's filter workgroup; 1 = copied by a kernel after the filter; 2 = filtered again),
+   "place_ptr" (diagnostic: a device buffer of 2 x tiles uint32 that the four-wave launch fills with the HW_ID /
+   XCC_ID of each tile's two live waves, 0 = off; tests/test_gpu_fullsize.py checks the SIMD placement with it),
    "fir_stream" (matched filter of <= 41 taps on complex64 / int16 input: 2 = default, persistent fir_strip_kernel;
    1 = fir_stream_kernel, one chunk per workgroup; 0 = round 1's tap-blocked fir_tile_kernel; same bits) */
 

@@ -191,3 +191,41 @@ def test_one_burst_beyond_4gib_of_output_rows(ctx, oracle):
     assert np.array_equal(r["rec"][0, :n], rec)
     out = oracle.fll_func(rec, 1e-6, 1)
     assert np.array_equal(r["dec"][0, :n], oracle.quadrants(out[0]))
+
+
+def test_four_wave_launch_places_live_waves_on_distinct_simds(ctx):
+    """Two workgroups per CU (512 tiles): the two-wave kernel is launched with four waves per tile, one on
+    each SIMD, and a per-CU ticket decides which SIMD pair keeps its waves (DESIGN.md 3.1 finding 5).  The
+    kernel reports where each tile's live waves run (option "place_ptr"): on every CU that holds two tiles
+    the four live waves sit on four different SIMDs, and a tile's two waves never share one."""
+    from dsp_amd.pipeline import BurstPipeline
+    B = 32768
+    pipe = BurstPipeline(ctx, B, 256, 4)
+    pipe.generate(SEED, b0=0)
+    pipe.matched_filter(free_raw=True)
+    nt = B // 64
+    d = ctx.malloc(nt * 2 * 4)
+    try:
+        ctx.memset(d, 0, nt * 2 * 4)
+        ctx.set_option("place_ptr", d)
+        pipe.run()
+        ctx.synchronize()
+        ctx.set_option("place_ptr", 0)
+        w = np.empty((nt, 2), np.uint32)
+        ctx.d2h(w, d)
+    finally:
+        ctx.set_option("place_ptr", 0)
+        ctx.free(d)
+        pipe.close()
+    assert (w >> 31).all(), "every tile's two live waves reported (the four-wave launch was used)"
+    hw = w & 0xffff
+    simd = (hw >> 4) & 3
+    cu = ((w >> 16) & 15).astype(np.int64) * 4096 + (hw >> 8).astype(np.int64)      # XCC | SE, SH, CU
+    assert (cu[:, 0] == cu[:, 1]).all()
+    assert (simd[:, 0] != simd[:, 1]).all()
+    per_cu = {}
+    for t in range(nt):
+        per_cu.setdefault(int(cu[t, 0]), []).extend([int(simd[t, 0]), int(simd[t, 1])])
+    two = [v for v in per_cu.values() if len(v) == 4]
+    assert len(two) >= len(per_cu) // 2, "most CUs hold two tiles at 512 tiles"
+    assert all(len(set(v)) == 4 for v in two)
