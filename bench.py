@@ -171,7 +171,7 @@ def parse_args(argv=None):
     ap.add_argument("--bursts", type=int, default=JOB_BURSTS, help="bursts per GPU (weak) / in total (strong)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-other-mode", action="store_true", help="N > 1: do not also time the other scaling mode")
-    ap.add_argument("--fir-reps", type=int, default=5, help="timed matched-filter passes for roofline.chain")
+    ap.add_argument("--fir-reps", type=int, default=10, help="timed matched-filter passes for roofline.chain")
     ap.add_argument("--lean", action="store_true",
                     help="also time the launch with decisions as the only output (informational; off by "
                          "default so that every launch of a profiled run is the measured one)")
@@ -234,7 +234,8 @@ def rank_main(args):
     # ---- synthetic bursts generated on the device, matched-filtered, resident in HBM ----
     pipe = BurstPipeline(ctx, B_res, N_SYM, SPS, alpha=ALPHA, Bn=BN, y=Y, interp_half_len=args.interp_half_len)
     pipe.generate(SEED, b0=b_lo)
-    pipe.matched_filter()                      # warm-up pass (first launch of the kernel)
+    for _ in range(max(1, args.warmup)):       # untimed passes, as many as the fused kernel gets
+        pipe.matched_filter()
     ctx.synchronize()
     ctx.timer_start()
     for _ in range(max(1, args.fir_reps)):

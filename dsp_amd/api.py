@@ -364,7 +364,12 @@ def sync_capture_segmented(x, sps=4, alpha=0.007, mu_initial=0.0, Bn=0.003, y=1,
     hw1/gardner.py:77-91).  taps: matched filter applied as np.convolve(x, taps, 'same') /
     np.std over the whole capture (worker.py:173-178), None when x is already filtered.
     Returns a dict: dec uint8[n] quadrant indices, mu / freq float32[n] if wanted,
-    seg_info int32[S, 4] = (first kept row, end row, rotation, rows produced) per segment.
+    seg_info int32[S, 4] = (first kept row, end row, rotation, rows produced) per segment;
+    with freq also seam_dfreq float64[S-1] = |freq just after a seam - freq just before it|.
+    freq is a PER-WINDOW quantity: fll_func's index restarts at every window start, so across a seam
+    the estimate jumps by what two loops that saw different pasts differ by -- a few standard
+    deviations of the loop's own estimate noise after a 4096-symbol warm-up at Bn = 0.003, more when
+    the warm-up is shorter than the loop's settling time.  Decisions and mu carry over.
     seg_len: samples per segment, a multiple of sps (None: auto_seg_len).
     acquire (default): every window starts its timing loop at the sampling phase whose strobes carry
     the most energy over its first 256 symbols (mu_initial is then unused); False: at mu_initial.
@@ -413,7 +418,18 @@ def sync_capture_segmented(x, sps=4, alpha=0.007, mu_initial=0.0, Bn=0.003, y=1,
         out["mu"] = mu[:nn]
     if freq is not None:
         out["freq"] = freq[:nn]
+        out["seam_dfreq"] = seam_frequency_steps(out["freq"], out["seg_info"])
     return out
+
+
+def seam_frequency_steps(freq, seg_info):
+    """|freq[first symbol of a share] - freq[last symbol of the share before it]| for every seam of a
+    stitched capture (shares = seg_info[:, 1] - seg_info[:, 0] symbols each, empty ones skipped)."""
+    share = (seg_info[:, 1] - seg_info[:, 0]).astype(np.int64)
+    at = np.cumsum(share)[:-1]
+    at = np.unique(at[(at > 0) & (at < len(freq))])
+    f = np.asarray(freq, dtype=np.float64)
+    return np.abs(f[at] - f[at - 1])
 
 
 def lagrange_resample(signal, positions, half_len=4, *, ctx=None):
