@@ -96,6 +96,37 @@ def launch(n, argv, timeout=900, script=None):
 
 
 # ---------------------------------------------------------------------------
+def capture_mode(ctx, log2_samples=30, warmup=4096):
+    """Informational (BASELINE.json configs[5]): ONE int16 IQ capture of 2^30 samples, generated on the
+    device, through the segment-parallel receiver (peak, RRC + whole-stream std, Gardner + FLL over the
+    windows, stitching); the second call is timed with HIP events, the decisions of the first 2^18 symbols
+    are checked against the transmitted ones.  tools/bench_capture.py is the same run as a program."""
+    import importlib.util
+    from dsp_amd.pipeline import CapturePipeline
+    spec = importlib.util.spec_from_file_location(
+        "bench_capture", os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "bench_capture.py"))
+    bc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bc)
+    n, tau0, drift = 1 << log2_samples, 0.3, 2.0e-8
+    pipe = CapturePipeline(ctx, n, SPS, seg_len=None, warmup=warmup)
+    try:
+        pipe.generate(bc.SEED, tau0=tau0, drift=drift)
+        ctx.synchronize()
+        pipe.run()                              # allocations, code objects
+        ctx.timer_start()
+        nsym = pipe.run()
+        ms = ctx.timer_stop()
+        rate, _ = bc.check_decisions(pipe, n // SPS, tau0, drift, SPS, 0, min(nsym - 8, 1 << 18))
+        assert abs(nsym - int(round(n * (1.0 + drift) / SPS))) <= 4 and rate > 0.999, (nsym, rate)
+        return {"workload": f"one int16 IQ capture of 2^{log2_samples} samples (4 sps QPSK, RRC 0.35, CFO 1.5e-4, "
+                            f"drifting timing, Es/N0 20 dB), segment-parallel: seg_len {pipe.seg_len}, "
+                            f"warm-up {warmup} symbols, decisions + mu out",
+                "segments": pipe.S, "symbols": nsym, "ms": ms, "Msamples_per_s": n / ms / 1e3,
+                "symbol_match_rate": rate}
+    finally:
+        pipe.close()
+
+
 def cpu_baseline(X, inv_std, seconds=12.0):
     """Oracle chain (gardner -> fll -> decisions) on the host cores, bounded sample."""
     import numpy as np
@@ -172,6 +203,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-other-mode", action="store_true", help="N > 1: do not also time the other scaling mode")
     ap.add_argument("--fir-reps", type=int, default=10, help="timed matched-filter passes for roofline.chain")
+    ap.add_argument("--no-capture", action="store_true",
+                    help="skip the informational capture-mode record (config.capture_2p30: one 2^30-sample int16 "
+                         "capture through the segment-parallel receiver, timed after everything else on rank 0)")
     ap.add_argument("--lean", action="store_true",
                     help="also time the launch with decisions as the only output (informational; off by "
                          "default so that every launch of a profiled run is the measured one)")
@@ -364,8 +398,11 @@ def rank_main(args):
         if not args.no_cpu and world == 1:
             nb = min(128, B // 64 * 64) or B
             line["cpu_baseline"] = cpu_baseline(pipe.fetch_input(0, nb), pipe.fetch_inv_std(0, nb))
-        print(json.dumps(line), flush=True)
     pipe.close()
+    if rank == 0:
+        if world == 1 and not args.no_capture:
+            line["config"]["capture_2p30"] = capture_mode(ctx)
+        print(json.dumps(line), flush=True)
     ctx.close()
     if dist is not None:
         dist.barrier()
