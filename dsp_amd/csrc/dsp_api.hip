@@ -431,11 +431,12 @@ static int count_nonnull(std::initializer_list<const void *> l)
 
 // x_tile_rows / x_tile0: SyncParams (segment-parallel mode lays its windows out overlapping; 0 / NULL for
 // the C-ABI's separate tiles)
-static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, const void *x_tile0);
+// idle_pass: SyncParams (the caller never reads the output columns of bursts of length 0)
+static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, const void *x_tile0, int idle_pass);
 
-int dsp_sync_tiles_dev(dsp_ctx *c, const dsp_sync_args *a) { return sync_tiles_run(c, a, 0, nullptr); }
+int dsp_sync_tiles_dev(dsp_ctx *c, const dsp_sync_args *a) { return sync_tiles_run(c, a, 0, nullptr, 0); }
 
-static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, const void *x_tile0)
+static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, const void *x_tile0, int idle_pass)
 {
     if (!c || !a) return fail(DSP_E_ARG, "ctx/args is NULL");
     if (a->B < 0 || a->B > (1 << 30)) return fail(DSP_E_ARG, "sync: bad B");
@@ -458,7 +459,7 @@ static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, c
     memset(&P, 0, sizeof(P));
     P.x = a->x; P.lens = a->lens; P.scale = a->scale;
     P.B = (int)a->B; P.in_rows = (int)a->in_rows; P.len_all = (int)a->N; P.sps = sps;
-    P.x_tile_rows = x_tile_rows > 0 ? x_tile_rows : P.in_rows; P.x_tile0 = x_tile0;
+    P.x_tile_rows = x_tile_rows > 0 ? x_tile_rows : P.in_rows; P.x_tile0 = x_tile0; P.idle_pass = idle_pass;
     P.alpha = a->alpha; P.mu0 = a->mu0; P.mu0_per = a->variant == DSP_GARDNER2 ? a->mu0_per : nullptr; P.half_len = a->variant == 2 ? 0 : a->interp_half_len;
     if (fll) dsp_fll_gains(a->Bn, a->y, &P.kp, &P.ki);
     P.i0 = a->i0; P.fll_in = a->fll_state_in; P.fll_out = a->fll_state_out;
@@ -1520,7 +1521,7 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
     sa.Bn = a->Bn; sa.y = a->y; sa.mu = a->mu ? d_mu.p : nullptr; sa.pos = d_pos.p; sa.dec = d_dec.as<uint8_t>(); sa.freq = a->freq ? d_freq.p : nullptr;
     sa.out_rows = out_rows; sa.n_out = d_nout.as<int32_t>(); sa.status = d_status.as<int32_t>();
     {
-        int rc = sync_tiles_run(c, &sa, win_stride, win_tile0);
+        int rc = sync_tiles_run(c, &sa, win_stride, win_tile0, 1);
         if (rc != DSP_OK) return rc;
     }
 

@@ -25,6 +25,7 @@ struct SyncParams {
     int B, in_rows, len_all, sps;
     int x_tile_rows;          // rows between row 0 of consecutive tiles (== in_rows unless the tiles' windows overlap)
     const void *x_tile0;      // tile 0's rows if they live elsewhere, or NULL
+    int idle_pass;            // bursts of length 0 may run as passenger lanes: nothing reads their output columns
     // Gardner
     double alpha;             // gardner2: alpha; ted: delta_mu
     double mu0;

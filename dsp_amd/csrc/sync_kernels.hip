@@ -161,6 +161,7 @@ struct Tile {
     const unsigned char *ring;    // LDS ring base (generic pointer)
     unsigned lds_base;            // LDS byte address of the ring
     int lane, RM, R, in_rows;
+    int col;                      // the column this lane reads (its own; a passenger lane reads another burst's)
     int win_lo, win_hi;           // rows [win_lo, win_hi) are valid in the ring
     int F;                        // DMA front: rows [0, F) have been issued
     double scale;
@@ -170,10 +171,10 @@ struct Tile {
     {
         IN v;
         if ((unsigned)(row - win_lo) < (unsigned)(win_hi - win_lo)) {
-            v = ((const IN *)ring)[(row & RM) * 64 + lane];
+            v = ((const IN *)ring)[(row & RM) * 64 + col];
         } else {
             int r = row < 0 ? 0 : (row >= in_rows ? in_rows - 1 : row);
-            v = xt[(size_t)r * 64 + lane];
+            v = xt[(size_t)r * 64 + col];
             asm volatile("" : "+v"(v));          // keep the load's wait inside this branch
         }
         cd z;
@@ -185,7 +186,7 @@ struct Tile {
     template <bool SC>
     __device__ __forceinline__ cd lds_at(int row) const
     {
-        IN v = ((const IN *)ring)[(row & RM) * 64 + lane];
+        IN v = ((const IN *)ring)[(row & RM) * 64 + col];
         cd z;
         z.re = SC ? (double)v.x * scale : (double)v.x;
         z.im = SC ? (double)v.y * scale : (double)v.y;
@@ -508,7 +509,7 @@ __device__ __forceinline__ void tile_init(Tile<IN> &tl, const SyncParams &P, uns
     tl.xt = tile_rows<IN>(P, tile);
     tl.ring = ring;
     tl.lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)ring;
-    tl.lane = lane; tl.R = P.ring_rows; tl.RM = P.ring_rows - 1; tl.in_rows = P.in_rows;
+    tl.lane = lane; tl.col = lane; tl.R = P.ring_rows; tl.RM = P.ring_rows - 1; tl.in_rows = P.in_rows;
     tl.win_lo = 0; tl.win_hi = 0; tl.F = 0; tl.scale = scale;
 }
 
@@ -695,8 +696,25 @@ __global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
     const int tile = blockIdx.x;
     const int b = tile * 64 + lane;
     const bool lane_ok = b < P.B;
-    const int len = lane_ok ? (P.lens ? P.lens[b] : P.len_all) : 0;
-    const double scale = (lane_ok && P.scale) ? P.scale[b] : 1.0;
+    int len = lane_ok ? (P.lens ? P.lens[b] : P.len_all) : 0;
+    // Passenger lanes (gardner2 variant).  The steady path needs every lane of the wave active, so one
+    // idle lane -- the padding lanes of a partly filled last tile, or an empty window of the capture
+    // mode -- would keep its whole tile on the slower per-lane path and make that tile the launch's
+    // straggler.  Such a lane runs as a CLONE of the tile's longest burst (same column, scale and start
+    // values, so it does whatever that burst does and never holds the wave up) and nothing it computes
+    // is reported: its output columns are padding (b >= B) or, for empty bursts, only when the caller
+    // says that they are never read (idle_pass: the capture mode's stitch skips empty windows).
+    bool pass = false;
+    int src = lane;                                                      // the lane a passenger copies
+    double scale = (lane_ok && P.scale) ? P.scale[b] : 1.0;
+    if (VARIANT == DSP_VARIANT_GARDNER2) {
+        int lmax = len;
+        for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(lmax, d); lmax = o > lmax ? o : lmax; }
+        pass = (!lane_ok || (P.idle_pass && len == 0)) && lmax > 0;
+        const int first = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(len == lmax)) - 1);
+        const double sc = __shfl(scale, first);
+        if (pass) { len = lmax; src = first; scale = sc; }
+    }
     const int out_rows = P.out_rows, sps = P.sps, T = P.T, TQ = P.TQ;
     const int cap_rows = out_rows - 1;   // the last output row is scratch
     const size_t obase = (size_t)tile * out_rows * 64 + lane;
@@ -763,6 +781,10 @@ __global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
         TimingConst tc;
         dspm::GState gs;
         timing_init(tc, gs, P, VARIANT, len, lane_ok, b);
+        if (VARIANT == DSP_VARIANT_GARDNER2) {
+            const double mu_src = __shfl(gs.mu, src);
+            if (pass) { gs.active = true; gs.mu = mu_src; tl.col = src; }
+        }
         dspm::LagrangeW LW;                             // H > 0: the per-lane code's barycentric weights
         const dspm::LagrangeW *Lp = nullptr;
         if (H > 0) { dspm::lagrange_weights(H, LW); Lp = &LW; }
@@ -856,8 +878,8 @@ __global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
         }
         n_rec += n_steady;
         if (lane_ok) {
-            if (P.n_out) P.n_out[b] = n_rec;
-            if (P.status) P.status[b] = overflow ? 1 : 0;
+            if (P.n_out) P.n_out[b] = pass ? 0 : n_rec;
+            if (P.status) P.status[b] = (overflow && !pass) ? 1 : 0;
         }
     } else {
         // =================== FLL wave ===================
@@ -867,13 +889,17 @@ __global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
             if (P.fll_in) { freq = P.fll_in[2 * b]; integ = P.fll_in[2 * b + 1]; }
             if (P.i0) i0 = P.i0[b];
         }
+        if (VARIANT == DSP_VARIANT_GARDNER2) {                           // a passenger starts where its model starts
+            const double f_s = __shfl(freq, src), g_s = __shfl(integ, src), i_s = __shfl(i0, src);
+            if (pass) { freq = f_s; integ = g_s; i0 = i_s; }
+        }
         const double kp = P.kp, ki = P.ki;
         const dspm::MathK MK = load_math_consts();
         OC *o_sig = (OC *)P.sig; OS *o_freq = (OS *)P.freq; OS *o_ef = (OS *)P.ef;
         uint8_t *o_dec = P.dec;
         if (VARIANT == DSP_VARIANT_GARDNER2) {       // recovered[0] = signal[0]
-            const bool have = lane_ok && len > 0;
-            IN v = xt[lane];
+            const bool have = (lane_ok || pass) && len > 0;
+            IN v = xt[src];
             cd r0; r0.re = (double)v.x * scale; r0.im = (double)v.y * scale;
             FllLane fo = fll_iter(MK, have, r0, i0, freq, integ, kp, ki);
             if (o_sig) st_cplx(o_sig + obase, fo.sr, fo.si);

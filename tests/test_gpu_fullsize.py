@@ -229,3 +229,39 @@ def test_four_wave_launch_places_live_waves_on_distinct_simds(ctx):
     two = [v for v in per_cu.values() if len(v) == 4]
     assert len(two) >= len(per_cu) // 2, "most CUs hold two tiles at 512 tiles"
     assert all(len(set(v)) == 4 for v in two)
+
+
+def test_partly_filled_tile_ignores_its_idle_columns(ctx, oracle):
+    """A partly filled last tile: its idle lanes run as passenger lanes (clones of the tile's longest
+    burst, so that the tile keeps the steady path) and never read their own input columns -- with those
+    columns overwritten by NaNs every output of every burst has the same bits, and the oracle's."""
+    from dsp_amd.pipeline import BurstPipeline
+    B = 64 * 5 + 23
+    pipe = BurstPipeline(ctx, B, 512, 4)
+    try:
+        pipe.generate(SEED, b0=0)
+        pipe.matched_filter(free_raw=True)
+        pipe.run()
+        names = ("dec", "mu", "freq", "rec", "err")
+        before = {k: pipe.fetch(k, 0, B) for k in names}
+        n_before = pipe.n_out().copy()
+        # the last tile's rows [rows][64]: poison lanes 23..63
+        nbytes = pipe.rows * 64 * 8
+        tile = np.empty(pipe.rows * 64, np.complex64)
+        last = pipe.d_tiles + 5 * nbytes
+        ctx.d2h(tile, last)
+        t2 = tile.reshape(pipe.rows, 64)
+        t2[:, 23:] = np.nan + 1j * np.nan
+        ctx.h2d(last, tile)
+        pipe.run()
+        assert np.array_equal(pipe.n_out(), n_before) and (n_before == 512).all()
+        for k in names:
+            assert np.array_equal(pipe.fetch(k, 0, B), before[k]), k
+        X = pipe.fetch_input(320, B)
+        inv = pipe.fetch_inv_std(320, B)
+        for b in (0, 11, 22):
+            o = oracle.sync_chain_c64(X[b], scale=inv[b])
+            assert np.array_equal(before["dec"][320 + b, :o["n"]], o["dec"])
+            assert np.array_equal(before["mu"][320 + b, :o["n"] - 1], o["mu"].astype(np.float32))
+    finally:
+        pipe.close()
