@@ -242,6 +242,61 @@ def test_fuzz_segmented(ctx, oracle, trial):
     assert np.max(np.abs(got["freq"] - ref["freq"]), initial=0) < 1e-9
 
 
+@pytest.mark.parametrize("trial", range(12 * SCALE))
+def test_fuzz_capture_with_matched_filter(ctx, oracle, trial):
+    """The capture mode WITH the matched filter over random shapes of >= 64 segments: segment counts that
+    do not fill the last tile, streams that end inside a segment, warm-ups up to a whole segment, int16 and
+    complex64 input.  The pass over lane-major segment tiles (default) has the bits of the pass over the
+    overlapping windows, and the decisions follow the oracle's segmented definition."""
+    import dsp_amd
+    rng = np.random.default_rng(12000 + trial)
+    sps = int(rng.choice([2, 4, 4]))
+    seg_len = int(rng.choice([256, 512, 1024])) * sps
+    nseg = int(rng.integers(64, 200))
+    warm = int(rng.choice([0, 64, seg_len // sps // 2, seg_len // sps]))
+    i16 = bool(rng.integers(0, 2))
+    trim = int(rng.integers(0, seg_len // 4)) * 4 if rng.integers(0, 2) else 0
+    acquire = bool(rng.integers(0, 2))
+    n = nseg * seg_len - trim
+    h = dsp_amd.rrc_filter(sps, 10, 0.35)
+    nsym = n // sps + 8
+    q = rng.integers(0, 4, nsym)
+    sym = ((1 - 2 * (q & 1)) + 1j * (1 - 2 * (q >> 1))) / np.sqrt(2)
+    up = np.zeros(nsym * sps, complex)
+    up[::sps] = sym
+    tx = np.convolve(up, h, "same")[:n]
+    t = np.arange(n, dtype=float)
+    d = rng.uniform(0, sps) + 1e-6 * t
+    x = (np.interp(t - d, t, tx.real) + 1j * np.interp(t - d, t, tx.imag)) * np.exp(1j * (2 * np.pi * 1e-4 * t + 0.3))
+    x = x + 0.05 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    if i16:
+        pk = np.max(np.abs(np.concatenate((x.real, x.imag))))
+        w = np.empty(2 * n, np.int16)
+        w[0::2] = np.round(x.real / pk * 20000)
+        w[1::2] = np.round(x.imag / pk * 20000)
+        xin, xc = w, oracle.read_iq_int16_words(w, True)
+    else:
+        xin = x.astype(np.complex64)
+        xc = xin
+    outs = []
+    try:
+        for mode in (2, 0):
+            ctx.set_option("lead_copy", mode)
+            outs.append(dsp_amd.sync_capture_segmented(xin, sps, 0.007, 0.0, 0.003, 1, taps=h, seg_len=seg_len,
+                                                       warmup=warm, acquire=acquire, ctx=ctx))
+    finally:
+        ctx.set_option("lead_copy", 0)
+    a, b = outs
+    assert a["n"] == b["n"] and a["seg_info"].shape[0] == nseg
+    for k in ("dec", "mu", "freq", "seg_info"):
+        assert np.array_equal(a[k], b[k]), k
+    yf = oracle.convolve_same(xc, h)
+    ref = oracle.sync_capture_segmented(yf.astype(np.complex64), sps, 0.007, 0.0, 0.003, 1.0, seg_len=seg_len,
+                                        warmup=warm, scale=1.0 / oracle.np_std(yf), acquire=acquire)
+    assert b["n"] == ref["n"]
+    assert np.mean(b["dec"] == ref["dec"]) > 0.9995
+
+
 @pytest.mark.parametrize("trial", range(10 * SCALE))
 def test_fuzz_front_end(ctx, oracle, trial):
     """diff_corr, the preamble CFO estimators, the fourth-power estimator, derotation and the table
