@@ -254,62 +254,114 @@ __global__ __launch_bounds__(512) void seg_phase_k(const float2 *__restrict__ ti
     }
 }
 
-// 64 windows x 64 rows per workgroup through LDS so that both sides are contiguous
+// The kept rows [j0, j1) of every window, rotated and concatenated.  A workgroup takes 64 rows of one
+// tile -- one contiguous piece of each tiled array -- reads it with 16-byte loads (the next array's loads
+// are in flight while the current one goes out), turns it through LDS ([lane][row], one array after the
+// other in the same 17 KB) and writes, window by window, 64 consecutive outputs per wave (measured at
+// 2^30 samples: 64 rows 0.80 ms, 128 rows 0.97, 256 rows 1.35; round 1s 64 x 64 blocks with 4-byte loads 1.25).
+constexpr int GATHER_ROWS = 64;
+constexpr int GATHER_F4 = GATHER_ROWS * 16 / 256;            // 16-byte pieces of a 4-byte array per thread
+
+// rows [r_first, r_first + GATHER_ROWS) of a tile's 4-byte array; rows outside [0, n_rows) read as 0
+__device__ __forceinline__ void gather_load_f32(const float *__restrict__ tile_base, int r_first, int n_rows,
+                                                float4 (&v)[GATHER_F4])
+{
+#pragma unroll
+    for (int k = 0; k < GATHER_F4; k++) {
+        const int c = threadIdx.x + 256 * k;                 // piece c: row c / 16, lanes 4 * (c % 16) ..
+        const int row = r_first + (c >> 4);
+        v[k] = (row >= 0 && row < n_rows) ? *(const float4 *)(tile_base + (ptrdiff_t)row * 64 + (c & 15) * 4)
+                                          : float4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+__device__ __forceinline__ void gather_turn_f32(const float4 (&v)[GATHER_F4], float *lds)    // lds[lane][GATHER_ROWS + 1]
+{
+#pragma unroll
+    for (int k = 0; k < GATHER_F4; k++) {
+        const int c = threadIdx.x + 256 * k, i = c >> 4, l = (c & 15) * 4;
+        lds[(l + 0) * (GATHER_ROWS + 1) + i] = v[k].x; lds[(l + 1) * (GATHER_ROWS + 1) + i] = v[k].y;
+        lds[(l + 2) * (GATHER_ROWS + 1) + i] = v[k].z; lds[(l + 3) * (GATHER_ROWS + 1) + i] = v[k].w;
+    }
+}
+
 __global__ __launch_bounds__(256) void seg_gather_k(SegParams P, uint8_t *__restrict__ dec_out,
                                                     float *__restrict__ mu_out, float *__restrict__ freq_out,
                                                     int64_t capacity)
 {
-    __shared__ uint8_t td[64][68];
-    __shared__ float tm[64][65];
-    __shared__ float tf[64][65];
-    const int tile = blockIdx.y, r0 = blockIdx.x * 64;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __shared__ float buf[64 * (GATHER_ROWS + 1)];
+    __shared__ int s_j0[64], s_j1[64], s_rot[64];
+    __shared__ long long s_off[64];
+    const int tile = blockIdx.y, r0 = blockIdx.x * GATHER_ROWS;
+    const int lane = threadIdx.x & 63;
     {
         // rows no window of this tile keeps (the warm-up rows, mostly): nothing to read or write
         const int sw = tile * 64 + lane;
         const bool real = sw < P.n_slots && seg_of_slot(sw, P.map_tiles) < P.S;
         int lo = real ? P.j0[sw] : 0x7fffffff, hi = real ? P.j1[sw] : 0;
+        if (threadIdx.x < 64) {
+            s_j0[lane] = real ? lo : 0; s_j1[lane] = real ? hi : 0;      // an empty range for the idle slots
+            s_rot[lane] = real ? P.rot[sw] : 0; s_off[lane] = real ? P.off[sw] : 0;
+        }
         for (int d = 32; d >= 1; d >>= 1) {
             const int ol = __shfl_xor(lo, d), oh = __shfl_xor(hi, d);
             lo = ol < lo ? ol : lo; hi = oh > hi ? oh : hi;
         }
-        if (r0 + 64 <= lo || r0 >= hi) return;          // uniform over the workgroup
+        if (r0 + GATHER_ROWS <= lo || r0 >= hi) return;      // uniform over the workgroup
     }
+    const int rr = threadIdx.x % GATHER_ROWS, row = r0 + rr, bb0 = threadIdx.x / GATHER_ROWS;
+    constexpr int BBS = 256 / GATHER_ROWS;
+    const size_t tile_at = (size_t)tile * P.out_rows * 64;
+    // ---- all loads of the decisions and of mu first ----
+    constexpr int ND = GATHER_ROWS * 4 / 256;                // 16-byte pieces of the decisions per thread
+    uint4 vd[ND];
+    float4 vf[GATHER_F4];
+#pragma unroll
+    for (int k = 0; k < ND; k++) {
+        const int c = threadIdx.x + 256 * k, r = r0 + (c >> 2);
+        vd[k] = r < P.out_rows ? *(const uint4 *)(P.dec + tile_at + (size_t)r * 64 + (c & 3) * 16) : uint4{0, 0, 0, 0};
+    }
+    // mu history row r - 1 belongs to symbol row r
+    if (mu_out) gather_load_f32((const float *)P.mu + tile_at, r0 - 1, P.out_rows, vf);
+    else if (freq_out) gather_load_f32((const float *)P.freq + tile_at, r0, P.out_rows, vf);
     {
-        // all of a wave's loads first (16 rows x 3 arrays in flight), then the LDS stores
-        uint8_t vd[16];
-        float vm[16], vf[16];
-        const size_t at0 = ((size_t)tile * P.out_rows + r0 + w * 16) * 64 + lane;
+        uint8_t *lds8 = (uint8_t *)buf;                       // [lane][GATHER_ROWS + 4]
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int row = r0 + w * 16 + i;
-            const bool ok = row < P.out_rows;
-            const size_t at = at0 + (size_t)i * 64;
-            vd[i] = ok ? P.dec[at] : (uint8_t)0;
-            // mu history row r-1 belongs to symbol row r
-            vm[i] = (mu_out && ok && row > 0) ? ((const float *)P.mu)[at - 64] : 0.0f;
-            vf[i] = (freq_out && ok) ? ((const float *)P.freq)[at] : 0.0f;
-        }
+        for (int k = 0; k < ND; k++) {
+            const int c = threadIdx.x + 256 * k, i = c >> 2, l = (c & 3) * 16;
+            const unsigned w[4] = {vd[k].x, vd[k].y, vd[k].z, vd[k].w};
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int rr = w * 16 + i;
-            td[rr][lane] = vd[i];
-            tm[rr][lane] = vm[i];
-            tf[rr][lane] = vf[i];
+            for (int j = 0; j < 16; j++) lds8[(l + j) * (GATHER_ROWS + 4) + i] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
         }
+        __syncthreads();
+        for (int bb = bb0; bb < 64; bb += BBS) {
+            const int j0 = s_j0[bb], j1 = s_j1[bb];
+            if (row < j0 || row >= j1) continue;
+            const int64_t at = s_off[bb] + (row - j0);
+            if (at < capacity) dec_out[at] = (uint8_t)rot_quadrant(lds8[bb * (GATHER_ROWS + 4) + rr], s_rot[bb]);
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int i = 0; i < 16; i++) {
-        const int bb = w * 16 + i, s = tile * 64 + bb;            // a slot
-        if (s >= P.n_slots || seg_of_slot(s, P.map_tiles) >= P.S) continue;
-        const int row = r0 + lane;
-        const int j0 = P.j0[s], j1 = P.j1[s];
-        if (row < j0 || row >= j1) continue;
-        const int64_t at = P.off[s] + (row - j0);
-        if (at >= capacity) continue;
-        dec_out[at] = (uint8_t)rot_quadrant(td[lane][bb], P.rot[s]);
-        if (mu_out) mu_out[at] = tm[lane][bb];
-        if (freq_out) freq_out[at] = tf[lane][bb];
+    if (mu_out) {
+        gather_turn_f32(vf, buf);
+        if (freq_out) gather_load_f32((const float *)P.freq + tile_at, r0, P.out_rows, vf);
+        __syncthreads();
+        for (int bb = bb0; bb < 64; bb += BBS) {
+            const int j0 = s_j0[bb], j1 = s_j1[bb];
+            if (row < j0 || row >= j1) continue;
+            const int64_t at = s_off[bb] + (row - j0);
+            if (at < capacity) mu_out[at] = buf[bb * (GATHER_ROWS + 1) + rr];
+        }
+        __syncthreads();
+    }
+    if (freq_out) {
+        gather_turn_f32(vf, buf);
+        __syncthreads();
+        for (int bb = bb0; bb < 64; bb += BBS) {
+            const int j0 = s_j0[bb], j1 = s_j1[bb];
+            if (row < j0 || row >= j1) continue;
+            const int64_t at = s_off[bb] + (row - j0);
+            if (at < capacity) freq_out[at] = buf[bb * (GATHER_ROWS + 1) + rr];
+        }
     }
 }
 
@@ -420,7 +472,7 @@ hipError_t launch_seg_stitch(const SegParams &P, int overlap_vote, hipStream_t s
 hipError_t launch_seg_gather(const SegParams &P, uint8_t *dec_out, float *mu_out, float *freq_out,
                              int64_t capacity, hipStream_t s)
 {
-    dim3 grid((P.out_rows + 63) / 64, (P.n_slots + 63) / 64);
+    dim3 grid((P.out_rows + GATHER_ROWS - 1) / GATHER_ROWS, (P.n_slots + 63) / 64);
     hipLaunchKernelGGL(seg_gather_k, grid, dim3(256), 0, s, P, dec_out, mu_out, freq_out, capacity);
     return hipGetLastError();
 }
