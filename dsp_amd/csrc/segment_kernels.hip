@@ -95,9 +95,11 @@ __device__ __forceinline__ int rows_below(const SegParams &P, int s, int n, doub
 // one lane per window: the last symbol in front of the window's closing seam ends its share
 __global__ __launch_bounds__(64) void seg_scan_k(SegParams P)
 {
-    const int s = blockIdx.x * 64 + threadIdx.x;
+    // thread = slot, so that a wave's windows share a tile and its loads of a row coalesce
+    const int at = blockIdx.x * 64 + threadIdx.x;
+    if (at >= P.n_slots) return;
+    const int s = seg_of_slot(at, P.map_tiles);
     if (s >= P.S) return;
-    const int at = seg_slot(s, P.map_tiles);
     const int n = P.n_out[at];
     int j1 = n;
     if (s != P.S - 1) j1 = rows_below(P, at, n, (double)(s + 1) * (double)P.seg_len, true);
@@ -107,9 +109,11 @@ __global__ __launch_bounds__(64) void seg_scan_k(SegParams P)
 
 __global__ __launch_bounds__(64) void seg_range_k(SegParams P, int vote_len)
 {
-    const int s = blockIdx.x * 64 + threadIdx.x;
+    const int at = blockIdx.x * 64 + threadIdx.x;              // thread = slot (see seg_scan_k)
+    if (at >= P.n_slots) return;
+    const int s = seg_of_slot(at, P.map_tiles);
     if (s >= P.S) return;
-    const int at = seg_slot(s, P.map_tiles), before = seg_slot(s > 0 ? s - 1 : 0, P.map_tiles);
+    const int before = seg_slot(s > 0 ? s - 1 : 0, P.map_tiles);
     const int j1 = P.j1[at];
     int j0 = 0, rot = 0;
     if (s > 0) {
@@ -122,11 +126,20 @@ __global__ __launch_bounds__(64) void seg_range_k(SegParams P, int vote_len)
         if (V > jp) V = jp;
         // every pair of decisions agrees under exactly one of the four turns: one pass, four counters
         int agree[4] = {0, 0, 0, 0};
-        for (int m = 0; m < V; m++) {
-            const unsigned a = tile_u8(P.dec, P.out_rows, at, j0 - 1 - m);
-            const unsigned b = tile_u8(P.dec, P.out_rows, before, jp - 1 - m);
+        for (int m0 = 0; m0 < V; m0 += 8) {                 // eight pairs of loads in flight
+            unsigned a[8], b[8];
 #pragma unroll
-            for (int r4 = 0; r4 < 4; r4++) agree[r4] += rot_quadrant(a, r4) == b;
+            for (int i = 0; i < 8; i++) {
+                const int m = m0 + i < V ? m0 + i : V - 1;
+                a[i] = tile_u8(P.dec, P.out_rows, at, j0 - 1 - m);
+                b[i] = tile_u8(P.dec, P.out_rows, before, jp - 1 - m);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (m0 + i >= V) continue;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++) agree[r4] += rot_quadrant(a[i], r4) == b[i];
+            }
         }
         int best = -1;
 #pragma unroll
@@ -462,7 +475,7 @@ hipError_t launch_seg_phase(const void *tiles, int rows, const int *lens, int S,
 
 hipError_t launch_seg_stitch(const SegParams &P, int overlap_vote, hipStream_t s)
 {
-    const int nb = (P.S + 63) / 64;
+    const int nb = (P.n_slots + 63) / 64;
     hipLaunchKernelGGL(seg_scan_k, dim3(nb), dim3(64), 0, s, P);
     hipLaunchKernelGGL(seg_range_k, dim3(nb), dim3(64), 0, s, P, overlap_vote);
     hipLaunchKernelGGL(seg_offsets_k, dim3(1), dim3(1024), 0, s, P);
