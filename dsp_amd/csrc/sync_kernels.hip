@@ -427,6 +427,19 @@ __device__ __forceinline__ cd lagr_dot(const double (&L)[2 * H + 1], const cd (&
     return z;
 }
 
+template <int H, int OFF, int N>
+__device__ __forceinline__ cd lagr_dot_at(const double (&L)[2 * H + 1], const cd (&x)[N])   // taps on x[OFF .. OFF + 2H]
+{
+    static_assert(OFF + 2 * H + 1 <= N, "window inside the samples");
+    cd z; z.re = 0.0; z.im = 0.0;
+#pragma unroll
+    for (int i = 0; i < 2 * H + 1; i++) {
+        z.re = __builtin_fma(L[i], x[OFF + i].re, z.re);
+        z.im = __builtin_fma(L[i], x[OFF + i].im, z.im);
+    }
+    return z;
+}
+
 template <typename IN, bool SC, int H>
 __device__ __forceinline__ bool g2_steady_lagr(const Tile<IN> &tl, dspm::GState &gs, const TimingConst &tc,
                                                const dspm::LagrangeW *Lp, cd &rec, double &err, double &pos)
@@ -444,14 +457,26 @@ __device__ __forceinline__ bool g2_steady_lagr(const Tile<IN> &tl, dspm::GState 
     if (!__all(in)) return false;
     double L[T];
     lagr_basis<H>(f, L);
-    cd xa[T], xb[T], xc[T];
+    cd va, vb, vc, xc[T];
+    if (tc.sps == 4) {
+        // equal fractions: the instants are exactly 2 and 4 samples apart, so their 3 x (2H+1) samples are
+        // 2H+5 different ones -- each read and widened once (same products in the same order: same bits)
+        cd u[T + 4];
 #pragma unroll
-    for (int i = 0; i < T; i++) {
-        xa[i] = tl.template lds_at<SC>(r_a - H + i);
-        xb[i] = tl.template lds_at<SC>(r_b - H + i);
-        xc[i] = tl.template lds_at<SC>(r_c - H + i);
+        for (int i = 0; i < T + 4; i++) u[i] = tl.template lds_at<SC>(r_a - H + i);
+        va = lagr_dot_at<H, 0>(L, u); vb = lagr_dot_at<H, 2>(L, u); vc = lagr_dot_at<H, 4>(L, u);
+#pragma unroll
+        for (int i = 0; i < T; i++) xc[i] = u[4 + i];
+    } else {
+        cd xa[T], xb[T];
+#pragma unroll
+        for (int i = 0; i < T; i++) {
+            xa[i] = tl.template lds_at<SC>(r_a - H + i);
+            xb[i] = tl.template lds_at<SC>(r_b - H + i);
+            xc[i] = tl.template lds_at<SC>(r_c - H + i);
+        }
+        va = lagr_dot<H>(L, xa); vb = lagr_dot<H>(L, xb); vc = lagr_dot<H>(L, xc);
     }
-    const cd va = lagr_dot<H>(L, xa), vb = lagr_dot<H>(L, xb), vc = lagr_dot<H>(L, xc);
     const double e = dspm::ted_error(va, vb, vc);        // :87
     const double mu_n = mu - tc.alpha * e;               // :91
     const double i_o = kd + mu_n;                        // :95
