@@ -439,7 +439,7 @@ __global__ __launch_bounds__(64 * NW) void fir_stream_kernel(FirParams P)
 //   * every input sample is read from HBM ONCE: the FIR_MT - 1 samples two neighbouring chunks share
 //     stay in LDS (moved to the front of each row), only the chunk's CH new samples per burst are loaded
 //     (the chunk-per-workgroup kernels read W / CH = 1.36 x the input);
-//   * the loads of chunk c + 1 (16 bytes per lane, whole rows of 896 bytes) are issued before the
+//   * the loads of chunk c + 1 (two samples per lane, whole rows of 896 / 448 bytes) are issued before the
 //     arithmetic of chunk c and consumed after it, inside the same loop iteration, so the compiler's
 //     own vmcnt bookkeeping leaves the chunk's output stores in flight: a chunk's memory time hides
 //     behind its arithmetic instead of adding to it (the compute core alone saturates the fp64 issue
@@ -451,9 +451,12 @@ __global__ __launch_bounds__(64 * NW) void fir_stream_kernel(FirParams P)
 //     wave-uniform because the bursts are equally long.  A partly filled last tile is left to
 //     fir_stream_kernel (launch_fir_stream_t runs it over just that tile).
 // Outputs and per-output sums are the same bits as fir_stream_kernel / fir_tile_kernel.
-template <typename IN> struct Wide;                                   // 16 bytes of input samples
+// One load of a lane: two input samples (16 bytes of complex64, 8 bytes of int16 pairs).  Two, not four,
+// for the int16 pairs: the conversions and LDS writes of a row's new samples are wave instructions
+// whatever the number of lanes that take part, so 56 lanes x 2 samples cost half of 28 lanes x 4.
+template <typename IN> struct Wide;
 template <> struct Wide<f2v> { typedef float T __attribute__((ext_vector_type(4))); enum { SPL = 2 }; };
-template <> struct Wide<s2v> { typedef short T __attribute__((ext_vector_type(8))); enum { SPL = 4 }; };
+template <> struct Wide<s2v> { typedef short T __attribute__((ext_vector_type(4))); enum { SPL = 2 }; };
 __device__ __forceinline__ f2v wide_get(const Wide<f2v>::T &v, int i) { return i ? f2v{v.z, v.w} : f2v{v.x, v.y}; }
 __device__ __forceinline__ s2v wide_get(const Wide<s2v>::T &v, int i) { return s2v{v[2 * i], v[2 * i + 1]}; }
 
@@ -471,9 +474,9 @@ __global__ __launch_bounds__(512, 4) void fir_strip_kernel(FirParams P)
     typedef typename Wide<IN>::T WV;
     static_assert(sizeof(ST) == 8, "float32 staging");
     constexpr int NW = 8, RQ = 64 / NW, CH = OG * NW, HALO = FIR_MT - 1, W = CH + HALO;
-    constexpr int SPL = Wide<IN>::SPL;                  // samples per 16-byte load
+    constexpr int SPL = Wide<IN>::SPL;                  // samples per load
     constexpr int LPR = CH / SPL;                       // lanes that load a row's new samples
-    constexpr int WPR = W / SPL, NPL = (WPR + 63) / 64; // 16-byte pieces of a whole window, loads per row for them
+    constexpr int WPR = W / SPL, NPL = (WPR + 63) / 64; // pieces of a whole window, loads per row for them
     static_assert(CH % SPL == 0 && W % SPL == 0 && LPR <= 64, "one load per row and chunk");
     constexpr int NSH = (RQ * HALO + 63) / 64;          // halo samples a lane moves
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(512, 4) void fir_strip_kernel(FirParams P)
     const int len = P.len_all, rows = P.rows;
     int cnt = 0;                                        // outputs of this wave that count (wave-uniform)
 
-    // ---- the first chunk's whole window (16-byte pieces; a piece lies wholly inside or outside the burst:
+    // ---- the first chunk's whole window (two-sample pieces; a piece lies wholly inside or outside the burst:
     //      launch_fir_tile checks that the burst's ends fall on piece boundaries) ----------------
     {
         WV v[RQ][NPL];
@@ -984,10 +987,11 @@ static void fir_plan_strips(FirParams &P, int in_kind)
     P.cps = 0; P.edge = 0; P.tile0 = 0; P.rec0 = 0; P.strip_tiles = 0;
     P.nrec = P.nchunk; P.rec_full = P.nchunk;
     if (!P.stream || !P.strip_ok || P.starts || P.lens || P.skip_rows || P.feed_lead || P.stat_lo || P.stat_hi) return;
-    const int spl = in_kind == DSP_IN_I16 ? 4 : 2;                     // samples per 16 bytes
+    const int spl = 2;                                                 // samples per load (Wide<IN>)
     const int esz = in_kind == DSP_IN_I16 ? 4 : 8;
-    if (P.ld % spl || (P.start - (FIR_MT - 1)) % spl || ((uintptr_t)P.src & 15) || (P.ld * esz) % 16) return;
-    if (P.len_all % spl || P.rows < P.len_all || P.start < 0) return;   // the bursts' ends fall on 16-byte pieces
+    const int piece = spl * esz;                                       // bytes per load: 8 or 16
+    if (P.ld % spl || (P.start - (FIR_MT - 1)) % spl || ((uintptr_t)P.src % piece) || (P.ld * esz) % piece) return;
+    if (P.len_all % spl || P.rows < P.len_all || P.start < 0) return;   // the bursts' ends fall between two loads' pieces
     // (the stream may end anywhere inside the B segments, on a 16-byte piece: a cut segment and empty ones
     //  behind it are zeros to the filter and left out of its statistics)
     if (P.stream_mode && (P.B % 64 || P.ld != P.len_all || P.n_total > (int64_t)P.B * P.ld || P.n_total <= 0 ||
