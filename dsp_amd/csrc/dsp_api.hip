@@ -719,12 +719,13 @@ static int fir_tiles_run(dsp_ctx *c, const dsp_fir_args *a, void *ws, int64_t ws
         return fail(DSP_E_ARG, "fir: %d taps are too many for the LDS-tiled kernel", a->n_taps);
     P.h_pad = taps_buf; P.strip_ok = c->fir_stream == 2; P.n_cu = c->n_cu;
     const bool want_std = a->std_out || a->inv_std_out;
-    if (want_std && (!ws || ws_bytes < (int64_t)a->B * (P.nchunk + 8) * 32))
-        return fail(DSP_E_ARG, "fir: %s too small (need %lld bytes, have %lld)", ws_name,
-                    (long long)a->B * (P.nchunk + 8) * 32, (long long)ws_bytes);
     P.src = a->src; P.ld = a->src_stride; P.lens = a->lens; P.len_all = (int)a->N; P.B = (int)a->B;
     P.h = a->h; P.M = a->n_taps; P.start = a->start < 0 ? (a->n_taps - 1) / 2 : a->start;
     P.in_scale = a->in_scale; P.dst = a->tiles; P.rows = (int)a->rows; P.scale = a->scale;
+    if (a->in_kind == DSP_IN_C128 && c->fir_stream == 2) (void)fir_try_c128_strips(P);
+    if (want_std && (!ws || ws_bytes < (int64_t)a->B * (P.nchunk + 8) * 32))
+        return fail(DSP_E_ARG, "fir: %s too small (need %lld bytes, have %lld)", ws_name,
+                    (long long)a->B * (P.nchunk + 8) * 32, (long long)ws_bytes);
     P.stats = want_std ? (double *)ws : nullptr;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(launch_fir_tile(P, a->in_kind, c->stream));

@@ -115,7 +115,8 @@ struct FirParams {
                               //    of its successor (shift = starts[b+1] - starts[b]; successors in tiles > 0 only)
 };
 
-bool fir_plan(int in_kind, int M, int n_out, FirParams &P, bool allow_stream = true);
+bool fir_plan(int in_kind, int M, int n_out, FirParams &P, bool allow_stream = true, bool c128_stream = false);
+bool fir_try_c128_strips(FirParams &P);       // complex128: switch a filled P to the strip kernel's plan if it applies
 hipError_t launch_fir_tile(FirParams &P, int in_kind, hipStream_t s);
 // stream_mode requested: can fir_strip_kernel serve these parameters?  (false: clears stream_mode; the
 // caller falls back to the overlapping-window pass)

@@ -392,7 +392,6 @@ template <typename IN, typename OUT, int OG, int KS, int NW>
 __global__ __launch_bounds__(64 * NW) void fir_stream_kernel(FirParams P)
 {
     typedef typename Stage<IN>::T ST;
-    static_assert(sizeof(ST) == 8, "float32 staging");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int CH = OG * NW, W = CH + FIR_MT - 1;
     const int stride = P.stride;
@@ -457,8 +456,10 @@ __global__ __launch_bounds__(64 * NW) void fir_stream_kernel(FirParams P)
 template <typename IN> struct Wide;
 template <> struct Wide<f2v> { typedef float T __attribute__((ext_vector_type(4))); enum { SPL = 2 }; };
 template <> struct Wide<s2v> { typedef short T __attribute__((ext_vector_type(4))); enum { SPL = 2 }; };
+template <> struct Wide<d2v> { typedef double T __attribute__((ext_vector_type(2))); enum { SPL = 1 }; };   // one complex128
 __device__ __forceinline__ f2v wide_get(const Wide<f2v>::T &v, int i) { return i ? f2v{v.z, v.w} : f2v{v.x, v.y}; }
 __device__ __forceinline__ s2v wide_get(const Wide<s2v>::T &v, int i) { return s2v{v[2 * i], v[2 * i + 1]}; }
+__device__ __forceinline__ d2v wide_get(const Wide<d2v>::T &v, int) { return d2v{v.x, v.y}; }
 
 // STREAM: the "bursts" are the consecutive segments of ONE long stream (segment-parallel capture mode):
 // segment g = stream samples [g * ld, (g + 1) * ld), len_all == ld, and lane l of tile t is segment
@@ -467,17 +468,20 @@ __device__ __forceinline__ s2v wide_get(const Wide<s2v>::T &v, int i) { return s
 // after it the start of the following one: a window with warm-up and tail is a row range of that buffer
 // and every filtered sample is stored exactly once.  A segment's window sees its true neighbours across
 // the segment edges and zeros only beyond the stream's two ends.
+// complex128 input (the drop-in path's sample type) stages float64 pairs: 150 KB of LDS, one workgroup per
+// CU with up to 256 VGPRs, two loads per lane for a row's new samples -- that shape is HBM-bound (32 bytes
+// per sample in and out), not fp64-bound.
 template <typename IN, typename OUT, int OG, bool SCALED, bool STORE, bool STREAM = false>
-__global__ __launch_bounds__(512, 4) void fir_strip_kernel(FirParams P)
+__global__ __launch_bounds__(512, sizeof(typename Stage<IN>::T) == 16 ? 2 : 4) void fir_strip_kernel(FirParams P)
 {
     typedef typename Stage<IN>::T ST;
     typedef typename Wide<IN>::T WV;
-    static_assert(sizeof(ST) == 8, "float32 staging");
     constexpr int NW = 8, RQ = 64 / NW, CH = OG * NW, HALO = FIR_MT - 1, W = CH + HALO;
     constexpr int SPL = Wide<IN>::SPL;                  // samples per load
     constexpr int LPR = CH / SPL;                       // lanes that load a row's new samples
     constexpr int WPR = W / SPL, NPL = (WPR + 63) / 64; // pieces of a whole window, loads per row for them
-    static_assert(CH % SPL == 0 && W % SPL == 0 && LPR <= 64, "one load per row and chunk");
+    constexpr int NLD = (LPR + 63) / 64;                // loads per lane for a row's new samples
+    static_assert(CH % SPL == 0 && W % SPL == 0, "whole pieces");
     constexpr int NSH = (RQ * HALO + 63) / 64;          // halo samples a lane moves
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int stride = P.stride;
@@ -548,11 +552,17 @@ __global__ __launch_bounds__(512, 4) void fir_strip_kernel(FirParams P)
         // chunk c + 1's new samples (the last chunk of the strip loads its own again and drops them:
         // an unconditional load keeps the loop free of joins the compiler would wait at); pieces past
         // the burst's end re-read its last one and are zeroed when they go to LDS
-        WV pre[RQ];
+        WV pre[RQ][NLD];
         const int cn = c + 1 < c_hi ? c + 1 : c;
-        const int gn = cn * CH + P.start + (lane < LPR ? lane : LPR - 1) * SPL;     // first sample of this lane's piece
-        {
-            const int g = gn > len - SPL ? len - SPL : gn;
+        int gn[NLD];                                   // first sample of this lane's j-th piece
+#pragma unroll
+        for (int j = 0; j < NLD; j++) {
+            const int piece = lane + 64 * j;
+            gn[j] = cn * CH + P.start + (piece < LPR ? piece : LPR - 1) * SPL;
+        }
+#pragma unroll
+        for (int j = 0; j < NLD; j++) {
+            const int g = gn[j] > len - SPL ? len - SPL : gn[j];
 #pragma unroll
             for (int q = 0; q < RQ; q++) {
                 if (STREAM) {       // the next segment's samples follow in memory; only the stream ends
@@ -560,10 +570,10 @@ __global__ __launch_bounds__(512, 4) void fir_strip_kernel(FirParams P)
                     const int64_t row_at = (int64_t)row_burst(q) * P.ld;
                     const int64_t room = P.n_total - SPL - row_at;
                     const int lim = room > 0x7fffffff ? 0x7fffffff : (int)room;
-                    pre[q] = __builtin_nontemporal_load((const WV *)((const IN *)P.src + row_at + (gn > lim ? lim : gn)));
+                    pre[q][j] = __builtin_nontemporal_load((const WV *)((const IN *)P.src + row_at + (gn[j] > lim ? lim : gn[j])));
                 } else {
                     const IN *src = rows0 + (int64_t)q * P.ld + HALO - P.start;
-                    pre[q] = __builtin_nontemporal_load((const WV *)(src + g));
+                    pre[q][j] = __builtin_nontemporal_load((const WV *)(src + g));
                 }
             }
         }
@@ -615,26 +625,29 @@ __global__ __launch_bounds__(512, 4) void fir_strip_kernel(FirParams P)
                 const int idx = lane + 64 * j, q = idx / HALO, i = idx - q * HALO;
                 if (idx < RQ * HALO) myrows[q * stride + i] = keep[j];
             }
-            if (lane < LPR) {
-                // nothing to mask: the new samples lie inside the burst (inside the stream: row 63 holds
-                // the tile's last segment, 63 * ntiles + tile; if its samples are inside, every row's are)
-                const bool whole = STREAM ? ((int64_t)(63 * ntiles + tile) * P.ld + cn * CH + P.start + CH <= P.n_total)
-                                          : (cn * CH + P.start + CH <= len);
+            // nothing to mask: the new samples lie inside the burst (inside the stream: row 63 holds
+            // the tile's last segment, 63 * ntiles + tile; if its samples are inside, every row's are)
+            const bool whole = STREAM ? ((int64_t)(63 * ntiles + tile) * P.ld + cn * CH + P.start + CH <= P.n_total)
+                                      : (cn * CH + P.start + CH <= len);
+#pragma unroll
+            for (int j = 0; j < NLD; j++) {
+                const int piece = lane + 64 * j;
+                if (piece >= LPR) continue;
                 if (whole) {
 #pragma unroll
                     for (int q = 0; q < RQ; q++) {
 #pragma unroll
                         for (int u = 0; u < SPL; u++)
-                            myrows[q * stride + HALO + lane * SPL + u] = to_stage(wide_get(pre[q], u), isc);
+                            myrows[q * stride + HALO + piece * SPL + u] = to_stage(wide_get(pre[q][j], u), isc);
                     }
                 } else {
 #pragma unroll
                     for (int q = 0; q < RQ; q++) {
-                        const bool in = STREAM ? ((int64_t)row_burst(q) * P.ld + gn + SPL <= P.n_total)
-                                               : (gn + SPL <= len);
+                        const bool in = STREAM ? ((int64_t)row_burst(q) * P.ld + gn[j] + SPL <= P.n_total)
+                                               : (gn[j] + SPL <= len);
 #pragma unroll
                         for (int u = 0; u < SPL; u++)
-                            myrows[q * stride + HALO + lane * SPL + u] = in ? to_stage(wide_get(pre[q], u), isc) : ST{0, 0};
+                            myrows[q * stride + HALO + piece * SPL + u] = in ? to_stage(wide_get(pre[q][j], u), isc) : ST{0, 0};
                     }
                 }
             }
@@ -885,12 +898,12 @@ hipError_t launch_fir_stream_t(const FirParams &P, hipStream_t s)
     constexpr int OG = FIR_STREAM_OG, NW = 8, CH = OG * NW, W = CH + FIR_MT - 1, KS = (W + 63) / 64;
     if (P.CH != CH || P.W != W || !P.h_pad) return hipErrorInvalidValue;
     const int ntiles = (P.B + 63) / 64;
-    size_t lds = (size_t)64 * P.stride * 8;
+    size_t lds = (size_t)64 * P.stride * sizeof(typename Stage<IN>::T);            // 78 KB, 153 KB for complex128
     if (lds < (size_t)NW * 64 * 4 * 8) lds = (size_t)NW * 64 * 4 * 8;              // the statistics scratch
     hipLaunchKernelGGL(fir_pad_taps_k, dim3(1), dim3(64), 0, s, P.h, P.M, P.h_pad);
     void (*k)(FirParams) = fir_stream_kernel<IN, OUT, OG, KS, NW>;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
     if (P.cps > 0) {
@@ -951,10 +964,10 @@ hipError_t launch_fir_tile_t(const FirParams &P, hipStream_t s)
 }  // namespace
 
 // choose the chunk geometry; returns false if the filter is too long for the LDS-tiled kernel
-bool fir_plan(int in_kind, int M, int n_out, FirParams &P, bool allow_stream)
+bool fir_plan(int in_kind, int M, int n_out, FirParams &P, bool allow_stream, bool c128_stream)
 {
     P.stream = 0;
-    if (in_kind != DSP_IN_C128 && M <= FIR_MT && allow_stream) {
+    if ((in_kind != DSP_IN_C128 || c128_stream) && M <= FIR_MT && allow_stream) {
         // the stream kernel (fir_stream_kernel): 8 waves x FIR_STREAM_OG outputs per chunk
         P.stream = 1;
         P.CH = FIR_STREAM_OG * 8; P.W = P.CH + FIR_MT - 1; P.stride = P.W | 1;
@@ -987,8 +1000,8 @@ static void fir_plan_strips(FirParams &P, int in_kind)
     P.cps = 0; P.edge = 0; P.tile0 = 0; P.rec0 = 0; P.strip_tiles = 0;
     P.nrec = P.nchunk; P.rec_full = P.nchunk;
     if (!P.stream || !P.strip_ok || P.starts || P.lens || P.skip_rows || P.feed_lead || P.stat_lo || P.stat_hi) return;
-    const int spl = 2;                                                 // samples per load (Wide<IN>)
-    const int esz = in_kind == DSP_IN_I16 ? 4 : 8;
+    const int spl = in_kind == DSP_IN_C128 ? 1 : 2;                    // samples per load (Wide<IN>)
+    const int esz = in_kind == DSP_IN_I16 ? 4 : in_kind == DSP_IN_C128 ? 16 : 8;
     const int piece = spl * esz;                                       // bytes per load: 8 or 16
     if (P.ld % spl || (P.start - (FIR_MT - 1)) % spl || ((uintptr_t)P.src % piece) || (P.ld * esz) % piece) return;
     if (P.len_all % spl || P.rows < P.len_all || P.start < 0) return;   // the bursts' ends fall between two loads' pieces
@@ -1029,6 +1042,22 @@ bool fir_stream_mode_plan(FirParams &P, int in_kind)
     return P.stream_mode != 0;
 }
 
+// complex128 bursts: the persistent strip kernel (float64 staging, one workgroup per CU) where its plan
+// applies -- full tiles of equally long, 16-byte aligned bursts -- else P keeps fir_tile_kernel's plan.
+// P: every input field filled, planned by fir_plan(..., allow_stream = false).
+bool fir_try_c128_strips(FirParams &P)
+{
+    if (P.M > FIR_MT || P.B < 64) return false;
+    FirParams T = P;
+    if (!fir_plan(DSP_IN_C128, P.M, P.nchunk * P.CH, T, true, true) || !T.stream) return false;
+    T.nchunk = (P.len_all + T.CH - 1) / T.CH;
+    T.strip_ok = 1;
+    fir_plan_strips(T, DSP_IN_C128);
+    if (T.cps <= 0) return false;
+    P = T;
+    return true;
+}
+
 hipError_t launch_fir_tile(FirParams &P, int in_kind, hipStream_t s)
 {
     const int want_stream_mode = P.stream_mode;
@@ -1038,6 +1067,7 @@ hipError_t launch_fir_tile(FirParams &P, int in_kind, hipStream_t s)
         // the start of the zero-padded filter moves with the padding: none here (zeros are appended)
         if (in_kind == DSP_IN_I16) return launch_fir_stream_t<s2v, f2v>(P, s);
         if (in_kind == DSP_IN_C64) return launch_fir_stream_t<f2v, f2v>(P, s);
+        if (in_kind == DSP_IN_C128) return launch_fir_stream_t<d2v, d2v>(P, s);
         return hipErrorInvalidValue;
     }
     switch (in_kind) {
