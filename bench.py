@@ -223,6 +223,13 @@ def parse_args(argv=None):
 
 
 def rank_main(args):
+    # Exactly one line on stdout: libraries write there too (RCCL prints a five-line version banner when
+    # its first communicator is made, gloo its connection notes), so file descriptor 1 is pointed at
+    # stderr for the whole run and the JSON line goes out through a duplicate of the real stdout.
+    sys.stdout.flush()
+    real_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import numpy as np
     sys.path.insert(0, ROOT)
     from dsp_amd import sharding
@@ -402,7 +409,8 @@ def rank_main(args):
     if rank == 0:
         if world == 1 and not args.no_capture:
             line["config"]["capture_2p30"] = capture_mode(ctx)
-        print(json.dumps(line), flush=True)
+        real_out.write(json.dumps(line) + "\n")
+        real_out.flush()
     ctx.close()
     if dist is not None:
         dist.barrier()
