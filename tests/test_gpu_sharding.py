@@ -47,7 +47,9 @@ def test_bench_gpus_2_launches_its_own_ranks():
                         "--steps", "3", "--warmup", "1", "--no-cpu", "--fir-reps", "1"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    # stdout is the JSON line and nothing else (the process-group libraries print to stdout too)
+    assert len(r.stdout.splitlines()) == 1, r.stdout[:500]
+    line = json.loads(r.stdout)
     assert line["n_gpus"] == 2 and line["scaling"] == "weak"
     cfg = line["config"]
     assert cfg["bursts_total"] == 8192 and cfg["bursts_per_gpu"] == 4096
