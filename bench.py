@@ -237,7 +237,23 @@ def rank_main(args):
     rank, world, local = sharding.rank_env()
     # several ranks on one device (rehearsal on a one-GPU box) cannot form an RCCL group
     backend = os.environ.get("DSP_BENCH_BACKEND", "gloo" if "DSP_BENCH_DEVICE" in os.environ else "nccl")
-    dist = sharding.init_clock_group(world, local, backend)
+    try:
+        dist = sharding.init_clock_group(world, local, backend)
+        if dist is not None:
+            dist.barrier()
+    except Exception as e:                      # RCCL would not come up: the clocks can be aligned over gloo as well
+        if backend != "nccl":
+            raise
+        print(f"bench.py: RCCL process group failed ({type(e).__name__}: {e}); aligning clocks over gloo",
+              file=sys.stderr, flush=True)
+        try:
+            import torch.distributed as _d
+            if _d.is_initialized():
+                _d.destroy_process_group()
+        except Exception:
+            pass
+        backend = "gloo"
+        dist = sharding.init_clock_group(world, local, backend)
     red_dev = "cuda" if (dist is not None and backend == "nccl") else "cpu"
 
     import dsp_amd
@@ -374,7 +390,7 @@ def rank_main(args):
            "bursts_per_gpu": B, "bursts_total": total, "samples_per_burst": N,
            "generator": "on-device, counter-based RNG", "min_symbol_match_rate": worst,
            "matched_filter_ms": fir_ms, "interp_half_len": args.interp_half_len,
-           "parallelism": f"bursts sharded x{world}, no collective",
+           "parallelism": f"bursts sharded x{world}, no collective" + (f" (clocks aligned over {backend})" if world > 1 else ""),
            args.scaling + "_scaling": mode_cfg}
     if other_rec:
         cfg[other + "_scaling"] = other_rec
