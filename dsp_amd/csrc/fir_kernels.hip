@@ -1078,12 +1078,60 @@ hipError_t launch_fir_tile(FirParams &P, int in_kind, hipStream_t s)
     return hipErrorInvalidValue;
 }
 
+// ... one wave per burst: few bursts with many records each (a single long burst: 1313 records merged by one
+// thread took 0.31 ms of a 9 ms call).  Lanes merge every 64th record, then pairs of lanes merge.
+__device__ __forceinline__ void chan_merge(double &n, double &mr, double &mi, double &m2, double nb, double br, double bi,
+                                           double b2)
+{
+    if (nb <= 0.0) return;
+    const double nn = n + nb;
+    const double dr = br - mr, di = bi - mi;
+    m2 += b2 + (dr * dr + di * di) * (n * nb / nn);
+    mr += dr * (nb / nn);
+    mi += di * (nb / nn);
+    n = nn;
+}
+__global__ __launch_bounds__(64) void fir_stats_finish_wave(const double *__restrict__ stats, int nrec, int cnt_a, int b_split,
+                                                            int cnt_b, int B, double *__restrict__ std_out,
+                                                            double *__restrict__ inv_out)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= B) return;
+    double n = 0.0, mr = 0.0, mi = 0.0, m2 = 0.0;
+    const int cnt = b < b_split ? cnt_a : cnt_b;
+    for (int c = lane; c < cnt; c += 64) {
+        const double *r = stats + ((size_t)b * nrec + c) * 4;
+        chan_merge(n, mr, mi, m2, r[0], r[1], r[2], r[3]);
+    }
+    for (int d = 1; d < 64; d <<= 1) {
+        const double on = __shfl_xor(n, d), or_ = __shfl_xor(mr, d), oi = __shfl_xor(mi, d), o2 = __shfl_xor(m2, d);
+        // both lanes of a pair merge (lower, upper) in that order, so they hold the same bits afterwards
+        if (lane & d) {
+            double tn = on, tr = or_, ti = oi, t2 = o2;
+            chan_merge(tn, tr, ti, t2, n, mr, mi, m2);
+            n = tn; mr = tr; mi = ti; m2 = t2;
+        } else {
+            chan_merge(n, mr, mi, m2, on, or_, oi, o2);
+        }
+    }
+    if (lane == 0) {
+        const double sd = n > 0.0 ? sqrt(m2 / n) : __builtin_nan("");
+        if (std_out) std_out[b] = sd;
+        if (inv_out) inv_out[b] = 1.0 / sd;
+    }
+}
+
 hipError_t launch_fir_stats_finish(const FirParams &P, double *std_out, double *inv_out, hipStream_t s)
 {
     // after launch_fir_tile: the bursts of the tiles the strips covered hold rec_full records, the others nchunk
     const int split = P.cps > 0 ? P.strip_tiles * 64 : 0;
-    hipLaunchKernelGGL(fir_stats_finish, dim3((P.B + 255) / 256), dim3(256), 0, s, P.stats, P.nrec, P.rec_full, split,
-                       P.nchunk, P.B, std_out, inv_out);
+    const int most = P.rec_full > P.nchunk ? P.rec_full : P.nchunk;
+    if (P.B <= 2048 && most >= 128)
+        hipLaunchKernelGGL(fir_stats_finish_wave, dim3(P.B), dim3(64), 0, s, P.stats, P.nrec, P.rec_full, split, P.nchunk,
+                           P.B, std_out, inv_out);
+    else
+        hipLaunchKernelGGL(fir_stats_finish, dim3((P.B + 255) / 256), dim3(256), 0, s, P.stats, P.nrec, P.rec_full, split,
+                           P.nchunk, P.B, std_out, inv_out);
     return hipGetLastError();
 }
 
