@@ -53,8 +53,11 @@ static void *g_scratch_addr[64];        // device address of `scratch` per devic
 
 static thread_local char g_err[512] = "";
 
+static bool g_cache_needs_sync = false;   // an entry point failed: work may still be in flight on its buffers
+
 static int fail(int code, const char *fmt, ...)
 {
+    g_cache_needs_sync = true;
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
@@ -71,10 +74,74 @@ static int fail(int code, const char *fmt, ...)
     } while (0)
 
 // RAII device buffer for the host-pointer entry points
+// Device blocks of the host-pointer entry points are kept for the next call instead of going back to the
+// driver: a single-burst call makes ~20 of them, and hipMalloc + hipFree (which waits for the device)
+// cost it about a millisecond.  A block is handed out again only after the call that used it has
+// returned, i.e. after that call synchronised its stream (an entry point that fails may return with work
+// in flight: the next release then waits for the device first).  Bounded: 1 GiB and 128 blocks per
+// process, blocks up to 256 MiB; dsp_trim gives everything back.  Contents are undefined, as hipMalloc's.
+struct DevCache {
+    struct Block { void *p; size_t n; int dev; };
+    std::mutex mu;
+    std::vector<Block> free_;
+    size_t bytes = 0;
+    hipError_t take(size_t n, void **p, size_t *cap, int *dev)
+    {
+        n = (n + 255) & ~(size_t)255;
+        if (!n) n = 256;
+        hipError_t e = hipGetDevice(dev);
+        if (e != hipSuccess) return e;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            int best = -1;
+            for (int i = 0; i < (int)free_.size(); i++)
+                if (free_[i].dev == *dev && free_[i].n >= n && free_[i].n <= 2 * n + 4096 &&
+                    (best < 0 || free_[i].n < free_[best].n)) best = i;
+            if (best >= 0) {
+                *p = free_[best].p; *cap = free_[best].n;
+                bytes -= free_[best].n;
+                free_.erase(free_.begin() + best);
+                return hipSuccess;
+            }
+        }
+        *cap = n;
+        return hipMalloc(p, n);
+    }
+    void give(void *p, size_t n, int dev)
+    {
+        if (g_cache_needs_sync) { (void)hipDeviceSynchronize(); g_cache_needs_sync = false; }
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (n <= ((size_t)256 << 20) && bytes + n <= ((size_t)1 << 30) && free_.size() < 128) {
+                free_.push_back(Block{p, n, dev});
+                bytes += n;
+                return;
+            }
+        }
+        (void)hipFree(p);
+    }
+    void clear(int dev)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        for (size_t i = 0; i < free_.size();) {
+            if (free_[i].dev == dev) {
+                (void)hipFree(free_[i].p);
+                bytes -= free_[i].n;
+                free_.erase(free_.begin() + i);
+            } else {
+                i++;
+            }
+        }
+    }
+};
+static DevCache *g_dev_cache = new DevCache;     // never destroyed: no hipFree after the runtime has shut down
+
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
+    size_t cap = 0;
+    int dev = 0;
+    ~DevBuf() { if (p) g_dev_cache->give(p, cap, dev); }
+    hipError_t alloc(size_t n) { return g_dev_cache->take(n, &p, &cap, &dev); }
     template <typename T> T *as() { return (T *)p; }
 };
 
@@ -221,6 +288,7 @@ int dsp_trim(dsp_ctx *c)
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     ctx_trim(c);
+    g_dev_cache->clear(c->device);
     return DSP_OK;
 }
 
