@@ -350,7 +350,9 @@ typedef struct dsp_capture_args {
 } dsp_capture_args;
 #define DSP_ACQUIRE_SYMBOLS 256
 /* The segment-parallel calls keep their large device work buffers (window tiles, per-window output
- * tiles) in the context between calls; dsp_trim releases them (dsp_destroy does too).           */
+ * tiles) in the context between calls; dsp_trim releases them (dsp_destroy does too).  The host-pointer
+ * entry points likewise keep their device blocks (<= 1 GiB per process) for the next call: dsp_trim returns
+ * those of the context's device as well.                                                            */
 int dsp_trim(dsp_ctx *ctx);
 /* The argument checks of the two calls below as a function of its own (no device needed): DSP_OK, or
  * DSP_E_ARG with the reason in dsp_last_error().  Limits: sps 1..64; seg_len a multiple of sps and
