@@ -579,7 +579,11 @@ static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, c
         if (R == 0) {
             R = (sps > 8 || P.half_len > 2) ? 128 : 64;
             // prefer a smaller ring when that lets every tile be resident at once
-            while (R > 32 && (size_t)R * 64 * elem + (split ? 2200 : 0) > budget &&
+            // (the ring alone has to stay inside the 64 KiB the LDS-DMA reaches; ring + queue inside the
+            //  tile's share -- a complex128 ring of 64 rows fills the 64 KiB and its queue lies above it:
+            //  a single complex128 burst ran 14 % slower on the 32-row ring this loop used to fall to)
+            while (R > 32 && ((size_t)R * 64 * elem > 64 * 1024 ||
+                              (size_t)R * 64 * elem + (split ? 2200 : 0) > budget_all) &&
                    sync_plan(elem, sps, P.half_len, a->variant, n_store, R / 2).use_ring)
                 R /= 2;
         }

@@ -34,6 +34,9 @@ def best(f, n=5):
 
 
 def main():
+    for kv in os.environ.get("DSP_LATENCY_OPTS", "").split(","):        # e.g. split=0,queue_block=8
+        if kv:
+            dsp_amd.default_context().set_option(kv.split("=")[0], int(kv.split("=")[1]))
     h = dsp_amd.rrc_filter(4, 10, 0.35)
     x1 = dsp_amd.read_iq_float32(os.path.join(D, "qpsk_high_snr_sps_4_float32.pcm")).astype(np.complex128)
     res = {}
