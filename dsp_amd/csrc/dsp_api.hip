@@ -577,7 +577,9 @@ static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, c
         const int n_store = split ? n_store_t : n_store_t + n_store_f;
         int R = c->ring_rows;
         if (R == 0) {
-            R = (sps > 8 || P.half_len > 2) ? 128 : 64;
+            // 128 rows (8 symbols per DMA block instead of 6: 2 % at up to two tiles per CU) wherever the
+            // share allows; the loop below comes back to 64 / 32 rows where it does not
+            R = 128;
             // prefer a smaller ring when that lets every tile be resident at once
             // (the ring alone has to stay inside the 64 KiB the LDS-DMA reaches; ring + queue inside the
             //  tile's share -- a complex128 ring of 64 rows fills the 64 KiB and its queue lies above it:
@@ -611,7 +613,9 @@ static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, c
         // two 2-wave workgroups per CU land on three SIMDs (sync_kernels.hip); the idle middle wave
         // spreads them over four.  Measured: 512 tiles 1.57 -> 1.30 ms; no gain at one workgroup per
         // CU, 3 % slower at three or four, and at eight the spare waves cost occupancy
-        P.spare_wave = c->spare_wave >= 0 ? c->spare_wave : (per_cu == 2 ? 2 : 0);
+        // (automatic only for the linear interpolator: the Lagrange variants of the four-wave launch
+        //  have never been run on a GPU and stay behind the explicit option)
+        P.spare_wave = c->spare_wave >= 0 ? c->spare_wave : (per_cu == 2 && P.half_len == 0 ? 2 : 0);
         P.cu_tickets = c->cu_tickets;
         P.place = c->place;
         lds += (size_t)2 * TQ * 64 * 17 + 16 + 32;       // + the four-wave launch's five selection words

@@ -136,6 +136,7 @@ class PipelineRunner:
     def __init__(self, ctx, lo, hi, n_sym=2048, sps=4, seed=20251114, want=("dec",), **kw):
         from .pipeline import BurstPipeline
         self.ctx, self.lo, self.hi, self.want = ctx, lo, hi, tuple(want)
+        self.n_sym = int(n_sym)
         self.pipe = BurstPipeline(ctx, hi - lo, n_sym, sps, **kw) if hi > lo else None
         if self.pipe:
             self.pipe.generate(seed, b0=lo)
@@ -157,7 +158,10 @@ class PipelineRunner:
     def result(self):
         if not self.pipe:
             return {}
-        out = {k: self.pipe.fetch(k, 0, self.hi - self.lo) for k in self.want}
+        # the rows a burst produced: n_sym symbols (mu / err: one per iteration, n_sym - 1); what lies
+        # beyond them in the device tiles is scratch, not part of the result
+        out = {k: self.pipe.fetch(k, 0, self.hi - self.lo)[:, :self.n_sym - (1 if k in ("mu", "err") else 0)]
+               for k in self.want}
         out["n_out"] = self.pipe.n_out()
         return out
 

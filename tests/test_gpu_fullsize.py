@@ -61,10 +61,11 @@ def test_pipeline_fullsize(ctx, oracle, B, split):
                 assert np.array_equal(rec[b, :n], o["rec"].astype(np.complex64))
                 assert np.max(np.abs(freq[b, :n] - o["freq"])) < 1e-9
         # idempotence: a second launch over the same input rewrites identical outputs
-        d1 = pipe.fetch("dec", 0, 64)
-        f1 = pipe.fetch("freq", 0, 64)
+        d1 = pipe.fetch("dec", 0, 64)[:, :2048]             # (rows past the 2048 symbols are scratch)
+        f1 = pipe.fetch("freq", 0, 64)[:, :2048]
         pipe.run()
-        assert np.array_equal(pipe.fetch("dec", 0, 64), d1) and np.array_equal(pipe.fetch("freq", 0, 64), f1)
+        assert np.array_equal(pipe.fetch("dec", 0, 64)[:, :2048], d1)
+        assert np.array_equal(pipe.fetch("freq", 0, 64)[:, :2048], f1)
         pipe.close()
     finally:
         ctx.set_option("split", -1)
@@ -106,7 +107,7 @@ def test_spare_wave_launch_bit_identical(ctx, oracle, variant):
         for sw in (0, 1, -1):                   # plain launch, one idle wave, two idle waves + CU ticket (auto)
             ctx.set_option("spare_wave", sw)
             pipe.run()
-            got[sw] = {k: pipe.fetch(k, 0, B) for k in ("dec", "mu", "freq", "rec")}
+            got[sw] = {k: pipe.fetch(k, 0, B)[:, :512 - (k == "mu")] for k in ("dec", "mu", "freq", "rec")}
             got[sw]["n"] = pipe.n_out().copy()
     finally:
         ctx.set_option("spare_wave", -1)
@@ -255,8 +256,8 @@ def test_partly_filled_tile_ignores_its_idle_columns(ctx, oracle):
         ctx.h2d(last, tile)
         pipe.run()
         assert np.array_equal(pipe.n_out(), n_before) and (n_before == 512).all()
-        for k in names:
-            assert np.array_equal(pipe.fetch(k, 0, B), before[k]), k
+        for k in names:                          # bits, not values: rows past n_out hold whatever was there (NaNs too)
+            assert pipe.fetch(k, 0, B).tobytes() == before[k].tobytes(), k
         X = pipe.fetch_input(320, B)
         inv = pipe.fetch_inv_std(320, B)
         for b in (0, 11, 22):
