@@ -105,7 +105,13 @@ struct DevCache {
             }
         }
         *cap = n;
-        return hipMalloc(p, n);
+        e = hipMalloc(p, n);
+        if (e == hipErrorOutOfMemory) {            // give the kept blocks back and try once more
+            (void)hipGetLastError();
+            clear(*dev);
+            e = hipMalloc(p, n);
+        }
+        return e;
     }
     void give(void *p, size_t n, int dev)
     {
