@@ -217,6 +217,24 @@ def test_auto_seg_len_rule():
     assert auto_seg_len(1 << 30, 4, 4096) == 32768
     assert auto_seg_len(1 << 28, 4, 4096) == 16384
     assert auto_seg_len(1 << 24, 4, 4096) == 4096
+    # rounded up: never a 513th tile of windows while one warm-up per segment still fits, whatever the length
+    rng = np.random.default_rng(3)
+    for n in [int(v) for v in rng.integers(1 << 29, 1 << 31, 50)] + [(1 << 30) - 1000, (1 << 30) + 4, 10 ** 9]:
+        for sps in (2, 4, 8):
+            s = auto_seg_len(n, sps, 2048)
+            assert s % sps == 0 and s % 4 == 0
+            if s >= 2048 * sps and s < max(2 * 2048, 8192) * sps:
+                assert -(-n // s) <= 512 * 64, (n, sps, s)
+
+
+def test_seam_frequency_steps():
+    """|freq| steps across the seams of a stitched capture, from the shares in seg_info (empty shares skipped)."""
+    from dsp_amd.api import seam_frequency_steps
+    info = np.array([[0, 3, 0, 5], [2, 2, 0, 4], [1, 5, 0, 6], [0, 2, 0, 2]], np.int32)    # shares 3, 0, 4, 2
+    freq = np.array([1.0, 1.0, 1.5, 2.0, 2.0, 2.0, 2.5, 1.0, 1.0], np.float32)
+    d = seam_frequency_steps(freq, info)
+    assert d.dtype == np.float64 and np.allclose(d, [0.5, 1.5])                           # seams at symbols 3 and 7
+    assert seam_frequency_steps(freq[:3], info[:1]).size == 0
 
 
 @pytest.mark.gpu
