@@ -146,32 +146,55 @@ def test_spare_wave_complex128_host_path(ctx):
 
 def test_more_tiles_than_lds_residency_allows(ctx):
     """B = 200 000 bursts = 3125 tiles, 13 per CU: more than the per-CU LDS can hold at once.  The
-    residency budget only steers the ring / queue sizes (the surplus tiles queue on the CUs); the
-    launch must not be refused, and every tile must produce the bits of a 64-burst call."""
+    launch must not be refused: the host issues such a batch as several launches of whole tiles
+    (option batch_split), and every tile must produce the bits of a 64-burst call.  Two different
+    tiles (samples, ragged lengths and per-burst scales all differ) alternate without a period, so a
+    launch that read or wrote another launch's tiles, lengths or scales would show."""
     import dsp_amd
     n_cu, lds = ctx.device_info()
     assert n_cu == 256 and lds == 160 * 1024                      # MI355X; the host code reads both
     rng = np.random.default_rng(17)
     n_sym = 24
-    q = rng.integers(0, 4, (64, n_sym))
-    sym = ((1 - 2 * (q & 1)) + 1j * (1 - 2 * (q >> 1))) / np.sqrt(2)
-    x64 = (np.repeat(sym, 4, axis=1) + 0.05 * (rng.standard_normal((64, 4 * n_sym))
-                                               + 1j * rng.standard_normal((64, 4 * n_sym)))).astype(np.complex64)
-    ref = dsp_amd.sync_chain_batch(x64, 4, 0.007, 0.0, 0.03, 1, ctx=ctx)
-    B = 200000
-    X = np.tile(x64, (B // 64, 1))
-    got = dsp_amd.sync_chain_batch(X, 4, 0.007, 0.0, 0.03, 1, ctx=ctx)
-    assert (got["n_out"] == np.tile(ref["n_out"], B // 64)).all()
-    for k in ("rec", "err", "mu", "sig", "freq", "ef", "dec"):
-        g = got[k].reshape(B // 64, 64, -1)
-        assert (g == ref[k][None]).all(), k
+
+    def tile64():
+        q = rng.integers(0, 4, (64, n_sym))
+        sym = ((1 - 2 * (q & 1)) + 1j * (1 - 2 * (q >> 1))) / np.sqrt(2)
+        x = (np.repeat(sym, 4, axis=1) + 0.05 * (rng.standard_normal((64, 4 * n_sym))
+                                                 + 1j * rng.standard_normal((64, 4 * n_sym)))).astype(np.complex64)
+        lens = rng.integers(4 * n_sym - 20, 4 * n_sym + 1, 64)
+        scale = rng.uniform(0.5, 2.0, 64)
+        return x, lens, scale
+
+    pats = [tile64(), tile64()]
+    names = ("rec", "err", "mu", "sig", "freq", "ef", "dec")
+
+    def check(B, cdt, outs, split):
+        nt = B // 64
+        sel = (rng.random(nt) < 0.5).astype(np.int64)
+        refs = [dsp_amd.sync_chain_batch(x.astype(cdt), 4, 0.007, 0.0, 0.03, 1, lens=l, scale=sc, outputs=outs, ctx=ctx)
+                for x, l, sc in pats]
+        X = np.stack([pats[0][0], pats[1][0]])[sel].reshape(B, -1).astype(cdt)
+        L = np.stack([pats[0][1], pats[1][1]])[sel].reshape(B)
+        S = np.stack([pats[0][2], pats[1][2]])[sel].reshape(B)
+        ctx.set_option("batch_split", split)
+        try:
+            got = dsp_amd.sync_chain_batch(X, 4, 0.007, 0.0, 0.03, 1, lens=L, scale=S, outputs=outs, ctx=ctx)
+        finally:
+            ctx.set_option("batch_split", 1)
+        n_ref = np.stack([refs[0]["n_out"], refs[1]["n_out"]])[sel].reshape(B)
+        assert (got["n_out"] == n_ref).all()
+        for k in outs:
+            g = got[k].reshape(nt, 64, -1)
+            r = np.stack([refs[0][k], refs[1][k]])[sel]
+            n = n_ref.reshape(nt, 64, 1) - (1 if k in ("err", "mu") else 0)
+            live = np.arange(g.shape[2])[None, None, :] < n          # rows past n_out are scratch
+            assert (np.where(live, g, 0) == np.where(live, r, 0)).all(), (k, split)
+
+    check(200000, np.complex64, names, 1)                         # three launches of 1280 / 1280 / 565 tiles
+    check(200000, np.complex64, ("rec", "dec"), 0)                # one launch, the surplus tiles queue on the CUs
     # the complex128 form reaches the limit at half as many tiles per CU
-    B2 = 96000
-    X2 = np.tile(x64.astype(np.complex128), (B2 // 64, 1))
-    ref2 = dsp_amd.sync_chain_batch(x64.astype(np.complex128), 4, 0.007, 0.0, 0.03, 1, outputs=("rec", "dec", "freq"), ctx=ctx)
-    got2 = dsp_amd.sync_chain_batch(X2, 4, 0.007, 0.0, 0.03, 1, outputs=("rec", "dec", "freq"), ctx=ctx)
-    for k in ("rec", "dec", "freq"):
-        assert (got2[k].reshape(B2 // 64, 64, -1) == ref2[k][None]).all(), k
+    check(128000, np.complex128, ("rec", "dec", "freq"), 1)       # 2000 tiles: two launches of 1024 / 976
+    check(96000, np.complex128, ("rec", "dec", "freq"), 1)        # 1500 tiles: one launch
 
 
 def test_one_burst_beyond_4gib_of_output_rows(ctx, oracle):
