@@ -8,6 +8,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -54,7 +55,7 @@ static void *g_scratch_addr[64];        // device address of `scratch` per devic
 
 static thread_local char g_err[512] = "";
 
-static bool g_cache_needs_sync = false;   // an entry point failed: work may still be in flight on its buffers
+static std::atomic<bool> g_cache_needs_sync{false};   // an entry point failed: work may still be in flight on its buffers
 
 static int fail(int code, const char *fmt, ...)
 {
@@ -116,7 +117,7 @@ struct DevCache {
     }
     void give(void *p, size_t n, int dev)
     {
-        if (g_cache_needs_sync) { (void)hipDeviceSynchronize(); g_cache_needs_sync = false; }
+        if (g_cache_needs_sync.exchange(false)) (void)hipDeviceSynchronize();
         {
             std::lock_guard<std::mutex> g(mu);
             if (n <= ((size_t)256 << 20) && bytes + n <= ((size_t)1 << 30) && free_.size() < 128) {

@@ -390,6 +390,34 @@ def test_gpu_segment_tiles_match_window_tiles(oracle, ctx, nseg, seg_len, warm, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("lead_copy", [0, 2])
+def test_gpu_more_windows_than_resident_tiles(ctx, lead_copy):
+    """100 032 windows = 1563 tiles, more than six per CU: the recurrence goes out as two launches of
+    whole tiles (option batch_split), over the lane-major segment tiles (lead_copy 0: the windows are
+    overlapping row ranges of one buffer and tile 0's warm-up rows live elsewhere) and over separate
+    window tiles (2).  Same bits as the single launch with the surplus tiles queued on the CUs."""
+    import dsp_amd
+    nseg, seg_len, warm = 100032, 256, 32
+    q, x, h = make_stream(400000, seed=5)
+    reps = nseg * seg_len // x.size + 1
+    x = np.tile(x.astype(np.complex64), reps)[:nseg * seg_len]       # period 6250 segments: not a whole number of tiles
+    outs = []
+    try:
+        ctx.set_option("lead_copy", lead_copy)
+        for split in (1, 0):
+            ctx.set_option("batch_split", split)
+            outs.append(dsp_amd.sync_capture_segmented(x, SPS, 0.007, 0.0, 0.003, 1, taps=h, seg_len=seg_len,
+                                                       warmup=warm, ctx=ctx))
+    finally:
+        ctx.set_option("lead_copy", 0)
+        ctx.set_option("batch_split", 1)
+    a, b = outs
+    assert a["seg_info"].shape[0] == nseg and a["n"] == b["n"] and a["n"] > 0.99 * (x.size // SPS)
+    for k in ("dec", "mu", "freq", "seg_info"):
+        assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.gpu
 def test_gpu_segmented_frequency_across_seams(oracle, stream, ctx):
     """What a caller may assume about `freq` across seams (SURVEY 8d asks for the seam steps to be
     reported): it is a per-window estimate.  The reported steps are those of the oracle's definition;
