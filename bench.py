@@ -215,7 +215,7 @@ def parse_args(argv=None):
     ap.add_argument("--ring-rows", type=int, default=0)
     ap.add_argument("--lds-pad", type=int, default=-1)
     ap.add_argument("--split", type=int, default=-1, help="-1 auto, 0 one wave per tile, 1 two")
-    ap.add_argument("--prio-period", type=int, default=0, help="priority rotation period (DMA blocks)")
+    ap.add_argument("--prio-period", type=int, default=-1, help="priority rotation period (DMA blocks; -1 auto, 0 off)")
     ap.add_argument("--queue-block", type=int, default=0, help="split kernel hand-off block (0 auto)")
     ap.add_argument("--spare-wave", type=int, default=-1,
                     help="split kernel, idle waves for SIMD balance: -1 auto (default), 0 never, 1 three waves, 2 four")
@@ -266,7 +266,7 @@ def rank_main(args):
     if args.lds_pad >= 0:
         ctx.set_option("lds_pad", args.lds_pad)
     ctx.set_option("split", args.split)
-    if args.prio_period:
+    if args.prio_period >= 0:
         ctx.set_option("prio_period", args.prio_period)
     if args.queue_block:
         ctx.set_option("queue_block", args.queue_block)

@@ -32,7 +32,7 @@ struct dsp_ctx {
                         // 1 = fir_stream_kernel, 0 = the tap-blocked kernel
     double *fir_taps;   // [64] the stream kernel's zero-padded taps
     void *static_scratch;   // this device's address of the static `scratch` array
-    int prio_period;    // split kernel: priority rotation period in DMA blocks (power of two), 0 = off
+    int prio_period;    // split kernel: priority rotation period in DMA blocks (power of two), 0 = off, -1 = automatic
     // grow-only device scratch kept between calls of the segment-parallel mode (its window tiles are
     // gigabytes: hipMalloc / hipFree per call cost milliseconds); released by dsp_trim / dsp_destroy
     void *scratch[8];
@@ -221,7 +221,7 @@ int dsp_create(int device_id, dsp_ctx **out)
     c->split = -1;
     c->batch_split = 1;
     c->queue_block = 0;
-    c->prio_period = 0;
+    c->prio_period = -1;
     c->spare_wave = -1;
     c->lead_copy = 0;
     c->fir_stream = 2;
@@ -351,7 +351,8 @@ int dsp_set_option(dsp_ctx *c, const char *name, int64_t value)
         if (value < -1 || value > 2) return fail(DSP_E_ARG, "spare_wave must be -1 (auto), 0, 1 or 2");
         c->spare_wave = (int)value;
     } else if (!strcmp(name, "prio_period")) {
-        if (value < 0 || value > 4096 || (value & (value - 1))) return fail(DSP_E_ARG, "prio_period must be 0 or a power of two");
+        if (value != -1 && (value < 0 || value > 4096 || (value & (value - 1))))
+            return fail(DSP_E_ARG, "prio_period must be -1 (auto), 0 or a power of two");
         c->prio_period = (int)value;
     } else if (!strcmp(name, "queue_block")) {
         if (value < 0 || value > 64) return fail(DSP_E_ARG, "queue_block must be in [0,64]");
@@ -663,7 +664,11 @@ static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, c
         }
         while (TQ > 1 && lds + (size_t)2 * TQ * 64 * 17 + 16 > room) TQ--;
         P.TQ = TQ;
-        P.prio_period = c->prio_period;
+        // From three tiles per CU on two or more waves share a SIMD and the arbiter's oldest-first choice lets
+        // some run ahead while others starve; rotating the four priority levels over the wave slots every 8
+        // DMA blocks evens that out (65 536 bursts 1.93 -> 1.87 ms, 98 304 2.91 -> 2.52 ms; nothing at up
+        // to two tiles per CU, where every wave has a SIMD to itself).  Scheduling only: same bits.
+        P.prio_period = c->prio_period >= 0 ? c->prio_period : (per_cu >= 3 ? 8 : 0);
         // two 2-wave workgroups per CU land on three SIMDs (sync_kernels.hip); the idle middle wave
         // spreads them over four.  Measured: 512 tiles 1.57 -> 1.30 ms; no gain at one workgroup per
         // CU, 3 % slower at three or four, and at eight the spare waves cost occupancy

@@ -54,7 +54,7 @@ int dsp_synchronize(dsp_ctx *ctx);
 int dsp_device_info(dsp_ctx *ctx, int32_t *n_cu, int64_t *lds_per_cu);
 int dsp_set_option(dsp_ctx *ctx, const char *name, int64_t value); /* tuning knobs: "ring_rows" (LDS ring rows, 0 auto),
    "lds_pad", "split" (-1 auto / 0 one wave per tile / 1 two), "queue_block" (hand-off block, 0 auto),
-   "prio_period" (rotate wave priorities every N DMA blocks, 0 off), "spare_wave" (two-wave kernel
+   "prio_period" (rotate wave priorities every N DMA blocks; -1 auto = 8 from three tiles per CU on, 0 off), "spare_wave" (two-wave kernel
    launched with idle waves so that two workgroups on a CU use four SIMDs: -1 auto = at two workgroups
    per CU, 0 never, 1 one idle wave, 2 two idle waves chosen by a per-CU ticket), "lead_copy" (segment-parallel mode, a window's warm-up rows: 0 = default: the stream is filtered once
    into lane-major segment tiles when it is a whole number of 64-segment tiles, else the warm-up rows are stored

@@ -124,6 +124,32 @@ def test_spare_wave_launch_bit_identical(ctx, oracle, variant):
     pipe.close()
 
 
+def test_priority_rotation_bit_identical(ctx):
+    """Three tiles per CU and more: the two-wave kernel rotates its waves' priorities (prio_period,
+    automatic from there on).  Scheduling only -- every output has the bits of the launch without it."""
+    from dsp_amd.pipeline import BurstPipeline
+    B = 53000                                   # 829 tiles, the last one partly filled: four per CU
+    pipe = BurstPipeline(ctx, B, 512, 4)
+    pipe.generate(SEED, b0=0)
+    pipe.matched_filter(free_raw=True)
+    got = {}
+    try:
+        for pp in (0, 2, -1):
+            ctx.set_option("prio_period", pp)
+            pipe.run()
+            got[pp] = {k: pipe.fetch(k, 0, B)[:, :512 - (k == "mu")] for k in ("dec", "mu", "freq", "rec", "sig")}
+            got[pp]["n"] = pipe.n_out().copy()
+    finally:
+        ctx.set_option("prio_period", -1)
+    n_min = int(got[0]["n"].min())             # rows past a burst's n_out are scratch
+    assert n_min > 500
+    for pp in (2, -1):
+        assert np.array_equal(got[0]["n"], got[pp]["n"])
+        for k in ("dec", "mu", "freq", "rec", "sig"):
+            assert np.array_equal(got[0][k][:, :n_min - 1], got[pp][k][:, :n_min - 1]), (pp, k)
+    pipe.close()
+
+
 def test_spare_wave_complex128_host_path(ctx):
     """The complex128 form of the kernel through the host-pointer entry point at two workgroups per CU."""
     import dsp_amd
