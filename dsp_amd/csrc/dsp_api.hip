@@ -28,6 +28,7 @@ struct dsp_ctx {
     int spare_wave;     // split kernel, idle waves for SIMD balance: -1 auto, 0 never, 1 three waves, 2 four waves + CU tickets
     unsigned *cu_tickets;   // [4096] per-CU workgroup counters for the four-wave launch
     unsigned *place;        // diagnostic (option "place_ptr"): caller's device buffer [tiles][2] for the live waves' HW_ID
+    int corr_window;    // preamble search: 1 = register-window kernel where it fits (default), 0 = diff_corr_kernel
     int fir_stream;     // matched filter of <= 41 taps: 2 = persistent fir_strip_kernel where eligible (default),
                         // 1 = fir_stream_kernel, 0 = the tap-blocked kernel
     double *fir_taps;   // [64] the stream kernel's zero-padded taps
@@ -225,6 +226,7 @@ int dsp_create(int device_id, dsp_ctx **out)
     c->spare_wave = -1;
     c->lead_copy = 0;
     c->fir_stream = 2;
+    c->corr_window = 1;
     c->fir_taps = nullptr;
 #ifdef DSP_TRACE
     c->trace = nullptr;
@@ -344,6 +346,8 @@ int dsp_set_option(dsp_ctx *c, const char *name, int64_t value)
     } else if (!strcmp(name, "fir_stream")) {
         if (value < 0 || value > 2) return fail(DSP_E_ARG, "fir_stream must be 0, 1 or 2");
         c->fir_stream = (int)value;
+    } else if (!strcmp(name, "corr_window")) {
+        c->corr_window = value != 0;
     } else if (!strcmp(name, "lead_copy")) {
         if (value < 0 || value > 2) return fail(DSP_E_ARG, "lead_copy must be 0, 1 or 2");
         c->lead_copy = (int)value;
@@ -1133,7 +1137,7 @@ int dsp_diff_corr(dsp_ctx *c, const void *x, int dtype, int64_t n, const double 
     HIP_TRY(d_c.alloc((size_t)sps * k_stride * 8));
     HIP_TRY(hipMemcpyAsync(d_x.p, x, (size_t)n * eb, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_p.p, dpre.data(), (size_t)L * 16, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(launch_diff_corr(d_x.p, dtype == DSP_C128, n, sps, d_p.p, L, d_c.p, k_stride, c->stream));
+    HIP_TRY(launch_diff_corr(d_x.p, dtype == DSP_C128, n, sps, d_p.p, L, d_c.p, k_stride, c->corr_window, c->stream));
     HIP_TRY(hipMemcpyAsync(conv_c64, d_c.p, (size_t)sps * k_stride * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DSP_OK;

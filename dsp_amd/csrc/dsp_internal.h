@@ -205,4 +205,4 @@ hipError_t launch_derotate_cut(const void *x, bool c128, const int64_t *offsets,
                                const double *f, int f_stride, int B, int64_t n_cut, void *out, int64_t out_stride,
                                hipStream_t s);
 hipError_t launch_diff_corr(const void *x, int c128, int64_t n, int sps, const void *dpre, int L, void *conv,
-                            int64_t kstride, hipStream_t s);
+                            int64_t kstride, int window, hipStream_t s);

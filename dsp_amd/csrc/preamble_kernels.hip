@@ -90,6 +90,105 @@ __global__ __launch_bounds__(256) void diff_corr_kernel(const IN *__restrict__ x
     }
 }
 
+// diff_corr_win_kernel: the same sums with the LDS reads shared between a thread's outputs.  A thread owns
+// DW_KB CONSECUTIVE k of one phase, so the D values of its outputs overlap: at tap j output o needs
+// d_phase[k0 + o + j], and a register window of DW_KB values, one new value per tap, serves all of them
+// (3 L / DW_KB + 2 LDS reads per output instead of 2.25 L: diff_corr_kernel is bound by its LDS reads).
+// D is kept per phase, Dp[phase][k] (row length odd, DW_KB odd: the lanes of a wave are consecutive
+// k-blocks of one phase, DW_KB words apart, and spread over all banks).  Workgroup = kblk = 256 / sps
+// k-blocks x sps phases = positions [K0 sps, (K0 + kblk DW_KB) sps).  Every sum runs in j order with the
+// expressions of diff_corr_kernel: the same bits.
+constexpr int DW_KB = 7;
+
+template <typename IN>
+__global__ __launch_bounds__(256) void diff_corr_win_kernel(const IN *__restrict__ x, int64_t n, int sps,
+                                                            const d2v *__restrict__ dpre, int L,
+                                                            f2v *__restrict__ conv, int64_t kstride, int kblk, int KP)
+{
+    constexpr int KB = DW_KB;
+    extern __shared__ d2v smem_dc[];
+    d2v *pre_s = smem_dc;                             // [L] conj(d_pre)
+    d2v *Dp = smem_dc + L;                            // [sps][KP], KP >= kblk KB + L (one value past the last window is loaded, never used)
+    const int nk = kblk * KB;                         // k per phase of this workgroup
+    const int64_t K0 = (int64_t)blockIdx.x * nk;
+    const int64_t i0 = K0 * sps;
+    for (int j = threadIdx.x; j < L; j += 256) pre_s[j] = d2v{dpre[j].x, -dpre[j].y};
+    const int ne = sps * (nk + L);                    // position order: coalesced loads
+    for (int e = threadIdx.x; e < ne; e += 256) {
+        const int64_t i = i0 + e;
+        const int kk = e / sps, p = e - kk * sps;
+        d2v d = {0.0, 0.0};
+        if (i + sps < n) {
+            const IN va = x[i], vb = x[i + sps];
+            const double ar = (double)va.x, ai = (double)va.y, br = (double)vb.x, bi = (double)vb.y;
+            d = d2v{br * ar + bi * ai, bi * ar - br * ai};            // b * conj(a)
+        }
+        Dp[p * KP + kk] = d;
+    }
+    __syncthreads();
+    const int phase = threadIdx.x / kblk, kb = threadIdx.x - phase * kblk;
+    if (phase >= sps) return;                         // 256 is not a multiple of sps: the last threads idle
+    const d2v *row = Dp + phase * KP + kb * KB;
+    double cr[KB], ci[KB], mr[KB], mi[KB], m2[KB];
+    d2v w[KB];
+#pragma unroll
+    for (int o = 0; o < KB; o++) { cr[o] = ci[o] = mr[o] = mi[o] = m2[o] = 0.0; w[o] = row[o]; }
+    // tap j + jj: output o reads window slot (o + jj) % KB = D value j + jj + o; slot jj is then refilled
+#define DW_TAP1(jj)                                                          \
+    {                                                                        \
+        const d2v pj = pre_s[j + jj];                                        \
+        _Pragma("unroll") for (int o = 0; o < KB; o++) {                     \
+            const d2v d = w[(o + jj) % KB];                                  \
+            cr[o] += d.x * pj.x - d.y * pj.y;                                \
+            ci[o] += d.x * pj.y + d.y * pj.x;                                \
+            mr[o] += d.x; mi[o] += d.y;                                      \
+        }                                                                    \
+        w[jj] = row[j + jj + KB];                                            \
+    }
+    int j = 0;
+    for (; j + KB <= L; j += KB) {
+#pragma unroll
+        for (int jj = 0; jj < KB; jj++) DW_TAP1(jj)
+    }
+#pragma unroll
+    for (int jj = 0; jj < KB; jj++)
+        if (j + jj < L) DW_TAP1(jj)
+#undef DW_TAP1
+#pragma unroll
+    for (int o = 0; o < KB; o++) { mr[o] /= (double)L; mi[o] /= (double)L; w[o] = row[o]; }
+#define DW_TAP2(jj)                                                          \
+    {                                                                        \
+        _Pragma("unroll") for (int o = 0; o < KB; o++) {                     \
+            const d2v d = w[(o + jj) % KB];                                  \
+            const double dr = d.x - mr[o], di = d.y - mi[o];                 \
+            m2[o] += dr * dr + di * di;                                      \
+        }                                                                    \
+        w[jj] = row[j + jj + KB];                                            \
+    }
+    for (j = 0; j + KB <= L; j += KB) {
+#pragma unroll
+        for (int jj = 0; jj < KB; jj++) DW_TAP2(jj)
+    }
+#pragma unroll
+    for (int jj = 0; jj < KB; jj++)
+        if (j + jj < L) DW_TAP2(jj)
+#undef DW_TAP2
+    // symbols of this phase: x[phase::sps] has ns entries, d has ns - 1
+    const int64_t ns = n > phase ? (n - phase + sps - 1) / sps : 0;
+    const int64_t nd = ns - 1;
+#pragma unroll
+    for (int o = 0; o < KB; o++) {
+        const int64_t k = K0 + kb * KB + o;
+        if (k >= kstride) continue;
+        f2v out = {0.f, 0.f};
+        if (k + L <= nd) {
+            const double Y = sqrt(m2[o] / (double)L);
+            if (Y > 0.0) out = f2v{(float)(cr[o] / Y), (float)(ci[o] / Y)};
+        }
+        conv[(int64_t)phase * kstride + k] = out;
+    }
+}
+
 // Fallback for preambles whose differential window does not fit LDS ((L - 1) * sps > ~9000): one
 // thread per (phase, k) straight from global memory.
 template <typename IN>
@@ -141,10 +240,32 @@ __global__ __launch_bounds__(256) void diff_corr_direct_kernel(const IN *__restr
 
 }  // namespace
 
+template <typename IN>
+static hipError_t launch_diff_corr_win(const IN *x, int64_t n, int sps, const d2v *dpre, int L, f2v *conv, int64_t kstride,
+                                       int kblk, int KP, size_t lds, hipStream_t s)
+{
+    const int64_t nk = (int64_t)kblk * DW_KB, nblk = (kstride + nk - 1) / nk;
+    if (nblk > 0x7fffffff) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)diff_corr_win_kernel<IN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(diff_corr_win_kernel<IN>, dim3((unsigned)nblk), dim3(256), lds, s, x, n, sps, dpre, L, conv, kstride, kblk, KP);
+    return hipGetLastError();
+}
+
 hipError_t launch_diff_corr(const void *x, int c128, int64_t n, int sps, const void *dpre, int L, void *conv,
-                            int64_t kstride, hipStream_t s)
+                            int64_t kstride, int window, hipStream_t s)
 {
     if (kstride <= 0 || sps <= 0) return hipSuccess;
+    if (window && sps <= 256) {                                 // register-window kernel where its LDS rows fit
+        const int kblk = 256 / sps;
+        const int KP = (kblk * DW_KB + L) | 1;                   // odd row length
+        const size_t lds_w = ((size_t)L + (size_t)sps * KP) * 16;
+        if (lds_w <= 144 * 1024)
+            return c128 ? launch_diff_corr_win((const d2v *)x, n, sps, (const d2v *)dpre, L, (f2v *)conv, kstride, kblk, KP, lds_w, s)
+                        : launch_diff_corr_win((const f2v *)x, n, sps, (const d2v *)dpre, L, (f2v *)conv, kstride, kblk, KP, lds_w, s);
+    }
     const int64_t total = kstride * sps;                       // positions i = phase + k sps to cover
     const int64_t nblk = (total + DC_OUT - 1) / DC_OUT;
     if (nblk > 0x7fffffff) return hipErrorInvalidValue;

@@ -63,6 +63,8 @@ int dsp_set_option(dsp_ctx *ctx, const char *name, int64_t value); /* tuning kno
    XCC_ID of each tile's two live waves, 0 = off; tests/test_gpu_fullsize.py checks the SIMD placement with it),
    "fir_stream" (matched filter of <= 41 taps on complex64 / int16 input: 2 = default, persistent fir_strip_kernel;
    1 = fir_stream_kernel, one chunk per workgroup; 0 = round 1's tap-blocked fir_tile_kernel; same bits),
+   "corr_window" (preamble search: 1 = default, each thread's outputs share their LDS reads through a register
+   window; 0 = round 1's diff_corr_kernel; same bits),
    "batch_split" (1 = default: a recurrence batch of more than six tiles per CU is issued as equal launches
    of whole tiles; 0 = always one launch, the surplus tiles queue on the CUs; same bits) */
 

@@ -146,6 +146,39 @@ def test_diff_corr_shapes(oracle, n_pre, sps, nsym):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_pre,sps,nsym,c64", [
+    (64, 4, 11000, True), (64, 4, 3000, False), (2, 1, 50, False), (3, 1, 5000, True), (8, 2, 777, False),
+    (9, 3, 4001, True), (200, 7, 2500, False), (15, 5, 300, True), (300, 32, 340, False), (33, 64, 200, True),
+    (130, 64, 180, False), (1000, 2, 9000, True),
+])
+def test_diff_corr_window_kernel_same_bits(ctx, n_pre, sps, nsym, c64):
+    """The register-window kernel (a thread's outputs share their LDS reads) against round 1's kernel:
+    the same sums in the same order, so the same bits -- lengths that end inside a workgroup's block,
+    taps that are not a multiple of the window, one to sixty-four phases, both sample types.  (The last
+    but one shape is too long for the window kernel's LDS rows and runs the older kernels either way.)"""
+    import dsp_amd
+    rng = np.random.default_rng(n_pre * 131 + sps)
+    n = nsym * sps + (sps // 2)
+    pre = np.exp(1j * np.pi / 2 * rng.integers(0, 4, n_pre))
+    x = 0.5 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    x[7 * sps + 1:7 * sps + 1 + n_pre * sps:sps] += pre[:len(x[7 * sps + 1:7 * sps + 1 + n_pre * sps:sps])] * np.exp(0.3j)
+    if c64:
+        x = x.astype(np.complex64)
+    got = {}
+    try:
+        for w in (0, 1):
+            ctx.set_option("corr_window", w)
+            got[w] = dsp_amd.diff_corr(x, pre, sps, ctx=ctx)
+    finally:
+        ctx.set_option("corr_window", 1)
+    assert len(got[0]) == len(got[1]) == sps
+    for p in range(sps):
+        assert got[0][p].shape == got[1][p].shape
+        assert np.array_equal(got[0][p].view(np.uint32), got[1][p].view(np.uint32)), p
+    assert n_pre == 2 or any(np.abs(g).max(initial=0) > 0 for g in got[1])      # one difference: its std is 0, all zeros
+
+
+@pytest.mark.gpu
 def test_demo_worker_script():
     """tools/demo_worker.py = the reference's test_worker.py flow (interp=True): five noise-free packets
     found half a sample apart on the doubled grid, every packet received and decided correctly."""

@@ -2,7 +2,7 @@
 """Kernel time of the preamble search (dsp_diff_corr) on a long signal; run under
 rocprofv3 --kernel-trace --stats to read the kernel's own duration (the call includes H2D / D2H).
 
-    python tools/bench_diff_corr.py [log2_samples=24] [preamble_symbols=64]
+    python tools/bench_diff_corr.py [log2_samples=24] [preamble_symbols=64] [corr_window=1]
 """
 import os
 import sys
@@ -15,6 +15,8 @@ import dsp_amd  # noqa: E402
 
 lg = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+if len(sys.argv) > 3:
+    dsp_amd.default_context().set_option("corr_window", int(sys.argv[3]))
 rng = np.random.default_rng(0)
 n = 1 << lg
 x = (rng.standard_normal(n, dtype=np.float32) + 1j * rng.standard_normal(n, dtype=np.float32)).astype(np.complex64)
