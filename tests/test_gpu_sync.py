@@ -216,7 +216,11 @@ def test_chain_ragged_and_scale(ctx, oracle):
         assert np.array_equal(r["dec"][b, :n], o["dec"]), b
         assert np.array_equal(r["rec"][b, :n], o["rec"].astype(np.complex64)), b
         assert np.array_equal(r["mu"][b, :n - 1], o["mu"].astype(np.float32)), b
-        assert np.all(r["dec"][b, n:] == 0) and np.all(r["rec"][b, n:] == 0)
+        # outputs of the batched calls are zero beyond n_out[b] (n_out - 1 for err / mu)
+        for k in ("dec", "rec", "sig", "freq", "ef"):
+            assert np.all(r[k][b, n:] == 0), (k, b)
+        for k in ("err", "mu"):
+            assert np.all(r[k][b, max(n - 1, 0):] == 0), (k, b)
 
 
 def test_fll_batch_state_continuation(ctx, oracle):
