@@ -142,6 +142,9 @@ class BurstPipeline:
         return out
 
     def fetch(self, name, b_lo=0, b_hi=None):
+        """Output `name` of bursts [b_lo, b_hi), burst-major [.., out_rows - 1].  Row r of burst b is valid
+        for r < n_out()[b] (mu / err: n_out - 1); the device tiles are not cleared between runs, so what
+        lies beyond is scratch (the host-pointer entry points return zeros there)."""
         b_hi = self.B if b_hi is None else b_hi
         return self.fetch_tiles(self.d_out[name], _OUT_ELEM[name], self.out_rows, _OUT_DTYPE[name],
                                 b_lo, b_hi, self.out_rows - 1)

@@ -158,11 +158,18 @@ class PipelineRunner:
     def result(self):
         if not self.pipe:
             return {}
-        # the rows a burst produced: n_sym symbols (mu / err: one per iteration, n_sym - 1); what lies
-        # beyond them in the device tiles is scratch, not part of the result
-        out = {k: self.pipe.fetch(k, 0, self.hi - self.lo)[:, :self.n_sym - (1 if k in ("mu", "err") else 0)]
-               for k in self.want}
-        out["n_out"] = self.pipe.n_out()
+        # the rows a burst produced: n_out[b] symbols (mu / err: one per iteration, n_out[b] - 1; a timing
+        # slip makes that n_sym +- 1); what lies beyond them in the device tiles is scratch, not part of
+        # the result, and is returned as zeros
+        import numpy as np
+        n = self.pipe.n_out()
+        width = max(int(n.max(initial=0)), self.n_sym)
+        out = {}
+        for k in self.want:
+            a = self.pipe.fetch(k, 0, self.hi - self.lo)[:, :width]
+            live = np.arange(a.shape[1])[None, :] < (n - (1 if k in ("mu", "err") else 0))[:, None]
+            out[k] = np.where(live, a, np.zeros((), a.dtype))
+        out["n_out"] = n
         return out
 
     def close(self):
