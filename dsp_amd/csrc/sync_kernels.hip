@@ -97,27 +97,35 @@ __device__ __forceinline__ void st_cplx(d2v *p, double re, double im, bool keep 
     asm volatile("global_store_dwordx4 %0, %1, off" DSP_WIDE_STORE_PAD :: "v"(p), "v"(v) : "memory");
 }
 
-// stores through a wave-uniform base (SGPR pair) + 32-bit lane offset: no 64-bit VALU address math
-__device__ __forceinline__ void sst(const void *base, unsigned voff, float v)
-{
-    asm volatile("global_store_dword %0, %1, %2" :: "v"(voff), "v"(v), "s"(base) : "memory");
-}
-__device__ __forceinline__ void sst(const void *base, unsigned voff, double v)
-{
-    asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(voff), "v"(v), "s"(base) : "memory");
-}
-__device__ __forceinline__ void sst(const void *base, unsigned voff, f2v v)
-{
-    asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(voff), "v"(v), "s"(base) : "memory");
-}
-__device__ __forceinline__ void sst(const void *base, unsigned voff, d2v v)
-{
-    asm volatile("global_store_dwordx4 %0, %1, %2" DSP_WIDE_STORE_PAD :: "v"(voff), "v"(v), "s"(base) : "memory");
-}
-__device__ __forceinline__ void sst_b8(const void *base, unsigned voff, unsigned v)
-{
-    asm volatile("global_store_byte %0, %1, %2" :: "v"(voff), "v"(v), "s"(base) : "memory");
-}
+// stores through a wave-uniform base (SGPR pair) + 32-bit lane offset: no 64-bit VALU address math.
+// HAZARD (the cause of round 2's two GPU-box faults): a VMEM instruction must not read an SGPR within
+// 5 wait states of a VALU write to it.  The compiler keeps that distance for its own instructions but
+// cannot see inside asm text, and under register pressure it restores a spilled base with
+// `v_readlane_b32 s1, v127, 37` DIRECTLY in front of the asm: the store then goes through a
+// half-restored 64-bit address.  The guard is therefore part of the asm text: the base is copied by a
+// SALU move into a scalar temporary of the asm's own (SALU reads of VALU-written SGPRs are interlocked,
+// and a VMEM read of a SALU-written SGPR needs no wait), or -- DSP_SST_GUARD 2 -- five wait states are
+// spent in front of the store.  tools/isa_lint.py checks every build flavour's assembly for the rule.
+#ifndef DSP_SST_GUARD
+#define DSP_SST_GUARD 1
+#endif
+#if DSP_SST_GUARD == 1
+#define DSP_SST(OPC, TAIL)                                                                          \
+    unsigned long long tb;                                                                          \
+    asm volatile("s_mov_b64 %0, %3\n\t" OPC " %1, %2, %0" TAIL : "=&s"(tb) : "v"(voff), "v"(v), "s"(base) : "memory")
+#elif DSP_SST_GUARD == 2
+#define DSP_SST(OPC, TAIL)                                                                          \
+    asm volatile("s_nop 4\n\t" OPC " %0, %1, %2" TAIL :: "v"(voff), "v"(v), "s"(base) : "memory")
+#else   // 0: no guard -- round 2's text, for A/B timing only; the lint decides whether such a build may exist
+#define DSP_SST(OPC, TAIL)                                                                          \
+    asm volatile(OPC " %0, %1, %2" TAIL :: "v"(voff), "v"(v), "s"(base) : "memory")
+#endif
+__device__ __forceinline__ void sst(const void *base, unsigned voff, float v) { DSP_SST("global_store_dword", ""); }
+__device__ __forceinline__ void sst(const void *base, unsigned voff, double v) { DSP_SST("global_store_dwordx2", ""); }
+__device__ __forceinline__ void sst(const void *base, unsigned voff, f2v v) { DSP_SST("global_store_dwordx2", ""); }
+__device__ __forceinline__ void sst(const void *base, unsigned voff, d2v v) { DSP_SST("global_store_dwordx4", DSP_WIDE_STORE_PAD); }
+__device__ __forceinline__ void sst_b8(const void *base, unsigned voff, unsigned v) { DSP_SST("global_store_byte", ""); }
+#undef DSP_SST
 
 #define WCASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
 __device__ __forceinline__ void wait_vmcnt(int n)
