@@ -418,13 +418,15 @@ def rank_main(args):
                       "achieved": B * N * 8.25 / (lean_ms * 1e-3) / 1e9}},
     }
     if rank == 0:
-        if not args.no_cpu and world == 1:
+        if not args.no_cpu:
+            # N > 1: a 3-second sample (the other ranks wait at the closing barrier meanwhile)
             nb = min(128, B // 64 * 64) or B
-            line["cpu_baseline"] = cpu_baseline(pipe.fetch_input(0, nb), pipe.fetch_inv_std(0, nb))
+            line["cpu_baseline"] = cpu_baseline(pipe.fetch_input(0, nb), pipe.fetch_inv_std(0, nb),
+                                                seconds=12.0 if world == 1 else 3.0)
     pipe.close()
     if rank == 0:
-        if world == 1 and not args.no_capture:
-            line["config"]["capture_2p30"] = capture_mode(ctx)
+        if not args.no_capture:
+            line["config"]["capture_2p30"] = capture_mode(ctx)     # rank 0's GPU alone, whatever N is
         real_out.write(json.dumps(line) + "\n")
         real_out.flush()
     ctx.close()

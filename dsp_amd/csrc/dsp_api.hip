@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <atomic>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -52,15 +53,20 @@ struct dsp_ctx {
 #define DSP_STATIC_SCRATCH_BYTES (16u << 20)
 static __device__ __align__(256) unsigned char scratch[DSP_STATIC_SCRATCH_BYTES];
 static std::mutex g_scratch_mu;
-static void *g_scratch_addr[64];        // device address of `scratch` per device ordinal
+static std::map<int, void *> g_scratch_addr;   // device address of `scratch` per device ordinal
 
 static thread_local char g_err[512] = "";
 
-static std::atomic<bool> g_cache_needs_sync{false};   // an entry point failed: work may still be in flight on its buffers
+// A call that fails may return with work in flight on its device blocks (DevBuf); the blocks go back to
+// the cache as the call unwinds, on this thread, so the mark is per thread: the first release after a
+// failure waits for the block's own device.  Marked by every HIP failure, and by any other failure that
+// happens while the thread holds blocks (a plain argument error at an entry point's head costs nothing).
+static thread_local bool t_release_needs_sync = false;
+static thread_local int t_live_blocks = 0;
 
 static int fail(int code, const char *fmt, ...)
 {
-    g_cache_needs_sync = true;
+    if (code == DSP_E_HIP || t_live_blocks > 0) t_release_needs_sync = true;
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
@@ -118,7 +124,14 @@ struct DevCache {
     }
     void give(void *p, size_t n, int dev)
     {
-        if (g_cache_needs_sync.exchange(false)) (void)hipDeviceSynchronize();
+        if (t_release_needs_sync) {
+            t_release_needs_sync = false;
+            int cur = -1;
+            (void)hipGetDevice(&cur);
+            if (cur != dev) (void)hipSetDevice(dev);
+            (void)hipDeviceSynchronize();
+            if (cur >= 0 && cur != dev) (void)hipSetDevice(cur);
+        }
         {
             std::lock_guard<std::mutex> g(mu);
             if (n <= ((size_t)256 << 20) && bytes + n <= ((size_t)1 << 30) && free_.size() < 128) {
@@ -149,8 +162,13 @@ struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
     int dev = 0;
-    ~DevBuf() { if (p) g_dev_cache->give(p, cap, dev); }
-    hipError_t alloc(size_t n) { return g_dev_cache->take(n, &p, &cap, &dev); }
+    ~DevBuf() { if (p) { g_dev_cache->give(p, cap, dev); t_live_blocks--; } }
+    hipError_t alloc(size_t n)
+    {
+        hipError_t e = g_dev_cache->take(n, &p, &cap, &dev);
+        if (e == hipSuccess && p) t_live_blocks++;
+        return e;
+    }
     template <typename T> T *as() { return (T *)p; }
 };
 
@@ -250,12 +268,13 @@ int dsp_create(int device_id, dsp_ctx **out)
     if (e == hipSuccess) {
         // once per device, with that device current (hipSetDevice above)
         std::lock_guard<std::mutex> lk(g_scratch_mu);
-        if (device_id < 64 && !g_scratch_addr[device_id]) {
+        auto it = g_scratch_addr.find(device_id);
+        if (it == g_scratch_addr.end()) {
             void *p = nullptr;
             e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
-            if (e == hipSuccess) g_scratch_addr[device_id] = p;
+            if (e == hipSuccess) it = g_scratch_addr.emplace(device_id, p).first;
         }
-        if (device_id < 64) c->static_scratch = g_scratch_addr[device_id];
+        if (e == hipSuccess) c->static_scratch = it->second;
     }
     if (e != hipSuccess) {
         // release whatever was created before the step that failed
@@ -676,8 +695,6 @@ static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, c
         // two 2-wave workgroups per CU land on three SIMDs (sync_kernels.hip); the idle middle wave
         // spreads them over four.  Measured: 512 tiles 1.57 -> 1.30 ms; no gain at one workgroup per
         // CU, 3 % slower at three or four, and at eight the spare waves cost occupancy
-        // (automatic only for the linear interpolator: the Lagrange variants of the four-wave launch
-        //  have never been run on a GPU and stay behind the explicit option)
         P.spare_wave = c->spare_wave >= 0 ? c->spare_wave : (per_cu == 2 && P.half_len == 0 ? 2 : 0);
         P.cu_tickets = c->cu_tickets;
         P.place = c->place;

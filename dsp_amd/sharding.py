@@ -44,11 +44,12 @@ def rank_env(env=None):
     return rank, world, local
 
 
-def init_clock_group(world: int, local: int, backend: str = "nccl"):
+def init_clock_group(world: int, local: int, backend: str = "nccl", force: bool = False):
     """torch.distributed process group used for barriers and the MAX of the timings, or None
     for a single rank.  backend "nccl" is RCCL on ROCm (one GPU per rank); "gloo" works on the
-    CPU and when several ranks rehearse on one device."""
-    if world <= 1:
+    CPU and when several ranks rehearse on one device.  force: form the group for a single rank
+    too (tests/test_gpu_sharding.py runs the RCCL branch that way on a one-GPU box)."""
+    if world <= 1 and not force:
         return None
     import torch
     import torch.distributed as dist

@@ -212,8 +212,10 @@ int64_t dsp_fir_workspace_bytes(int in_kind, int64_t B, int64_t N, int n_taps);
 int dsp_fir_tiles_dev(dsp_ctx *ctx, const dsp_fir_args *args);
 
 /* dsp_fir_tiles_dev without any allocation -- NO COUNTERPART IN THE REFERENCE.  For callers that cannot
- * call hipMalloc or bring a workspace: code under HIP graph capture, tight serving loops, harnesses
- * that forbid allocation.  Same arguments, same kernels and bit-identical results, but args->workspace
+ * call hipMalloc or bring a workspace: tight serving loops, harnesses that forbid allocation, code
+ * that must not change the device's memory map (free memory is the same before and after a call:
+ * tests/test_zz_no_alloc.py).  Not exercised under hipStreamBeginCapture: besides its kernel launches
+ * the call makes hipSetDevice and hipFuncSetAttribute calls.  Same arguments, same kernels and bit-identical results, but args->workspace
  * / workspace_bytes are ignored: the partial statistics and the padded taps live in a static device
  * array of dsp_static_scratch_bytes() = 16 MiB that every GPU the library runs on holds until the
  * process ends.  A call that needs more -- 512 + B * (ceil(N / chunk) + 8) * 32 bytes when std_out /

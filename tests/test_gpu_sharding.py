@@ -44,7 +44,7 @@ def test_bench_gpus_2_launches_its_own_ranks():
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--bursts", "4096",
-                        "--steps", "3", "--warmup", "1", "--no-cpu", "--fir-reps", "1"],
+                        "--steps", "3", "--warmup", "1", "--no-capture", "--fir-reps", "1"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     # stdout is the JSON line and nothing else (the process-group libraries print to stdout too)
@@ -56,3 +56,17 @@ def test_bench_gpus_2_launches_its_own_ranks():
     assert cfg["strong_scaling"]["bursts_total"] == 4096 and cfg["strong_scaling"]["value"] > 0
     assert cfg["weak_scaling"]["value"] == line["value"]
     assert line["roofline"]["chain"]["frac"] < line["roofline"]["frac"]
+    # the N > 1 line is self-contained: the CPU baseline (a 3-second sample) rides on rank 0
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["kind"] == "port"
+
+
+def test_rccl_clock_group_with_one_rank():
+    """The `nccl` (= RCCL) branch of sharding.init_clock_group, which bench.py takes for N > 1 on a
+    multi-GPU node: group creation with device_id, barrier, MAX all-reduce of float64 on the device and
+    timed_region's fences -- with the one rank a one-GPU box can hold, in a child process."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(__import__("bench").free_port()),
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_rccl_single.py")],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    assert r.stdout.strip().endswith("ok")

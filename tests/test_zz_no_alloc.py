@@ -56,6 +56,45 @@ def _run(ctx, L, entry, X, taps, lens=None, want_std=True):
             ctx.free(p)
 
 
+def _free_bytes():
+    hip = C.CDLL("libamdhip64.so")
+    free, total = C.c_size_t(0), C.c_size_t(0)
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value
+
+
+def test_static_entry_point_leaves_free_memory_unchanged(ctx):
+    """No hipMalloc / hipFree inside the call: the device's free memory is the same before and after
+    (every buffer is the test's own, allocated before the first reading)."""
+    import dsp_amd
+    from dsp_amd._lib import FirArgs, check
+    L = dsp_amd.lib()
+    rng = np.random.default_rng(5)
+    B, N = 256, 2048
+    X = (rng.standard_normal((B, N)) + 1j * rng.standard_normal((B, N))).astype(np.complex64)
+    taps = dsp_amd.rrc_filter(4, 10, 0.35)
+    rows = int(L.dsp_tile_rows(N))
+    bufs = [ctx.malloc(n) for n in (X.nbytes, taps.nbytes, (B // 64) * rows * 64 * 8, B * 8, B * 8)]
+    try:
+        ctx.h2d(bufs[0], X)
+        ctx.h2d(bufs[1], taps)
+        f = FirArgs()
+        f.src = bufs[0]; f.in_kind = 0; f.start = -1; f.B = B; f.N = N; f.src_stride = N
+        f.h = bufs[1]; f.n_taps = taps.size; f.rows = rows; f.tiles = bufs[2]
+        f.std_out = bufs[3]; f.inv_std_out = bufs[4]
+        check(L.dsp_fir_tiles_static_dev(ctx.handle, C.byref(f)))      # first call: code objects loaded
+        ctx.synchronize()
+        before = _free_bytes()
+        for _ in range(3):
+            check(L.dsp_fir_tiles_static_dev(ctx.handle, C.byref(f)))
+            assert _free_bytes() == before                             # while the call's work is in flight
+        ctx.synchronize()
+        assert _free_bytes() == before
+    finally:
+        for p in bufs:
+            ctx.free(p)
+
+
 def test_static_scratch_entry_point_matches(ctx):
     import dsp_amd
     L = dsp_amd.lib()

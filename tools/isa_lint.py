@@ -205,17 +205,6 @@ def read_blocks(path):
     return funcs
 
 
-def merge(a, b):
-    """worst case (smallest age) per key; returns (merged, changed-versus-a)"""
-    out = dict(a)
-    changed = False
-    for k, v in b.items():
-        if k not in out or v < out[k]:
-            out[k] = v
-            changed = True
-    return out, changed
-
-
 def run_block(blk, state, findings, fname, path):
     st = dict(state)
     for ins in blk['ins']:

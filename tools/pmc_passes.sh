@@ -14,10 +14,11 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INS
            "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES GRBM_GUI_ACTIVE" \
            "FETCH_SIZE" "WRITE_SIZE"; do
     i=$((i+1))
-    rm -rf /tmp/pmc_$TAG_$i
+    rm -rf /tmp/pmc_${TAG}_$i
     timeout -s KILL 180 rocprofv3 --pmc $set -d /tmp/pmc_${TAG}_$i -o p --output-format csv -- "$@" > $O/pass$i.log 2>&1
-    f=$(find /tmp/pmc_${TAG}_$i -name '*counter_collection.csv' | head -1)
-    cp $f $O/pass$i.csv
+    n=$(find /tmp/pmc_${TAG}_$i -name '*counter_collection.csv' | wc -l)
+    [ "$n" = 1 ] || { echo "pass $i: $n counter files (expected 1), see $O/pass$i.log"; exit 1; }
+    cp "$(find /tmp/pmc_${TAG}_$i -name '*counter_collection.csv')" $O/pass$i.csv
 done
 python3 - $O "$KSUB" <<'PY' | tee $O/summary.txt
 import csv, sys, collections, glob, os

@@ -7,10 +7,11 @@
 Prints how the tiles were spread over XCDs / CUs / SIMDs and how long the waves lived,
 which is what decides whether a launch is balanced.  Never used by the product path.
 
-BROKEN SINCE ROUND 2: the first run of the trace build in round 2 faulted the GPU box (cause not
-found).  Do not run it on a shared machine before the build has been examined; the
-SIMD-placement check it was used for now lives in the product library (dsp_set_option("place_ptr"),
-tests/test_gpu_fullsize.py::test_four_wave_launch_places_live_waves_on_distinct_simds).
+History: the first run of this build in round 2 faulted the GPU box.  Cause (round 3, found in the ISA on
+the CPU): the stamps build's register pressure made the compiler restore a spilled store base with
+v_readlane directly in front of an inline-asm `global_store ... s[n:n+1]`, which needs 5 wait states after
+a VALU write of an SGPR; the stores' asm text now carries its own guard and `make trace` / `make stamps`
+link only after tools/isa_lint.py passed over their assembly.
 """
 import collections
 import ctypes as C
