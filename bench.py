@@ -217,6 +217,8 @@ def parse_args(argv=None):
     ap.add_argument("--split", type=int, default=-1, help="-1 auto, 0 one wave per tile, 1 two")
     ap.add_argument("--prio-period", type=int, default=-1, help="priority rotation period (DMA blocks; -1 auto, 0 off)")
     ap.add_argument("--queue-block", type=int, default=0, help="split kernel hand-off block (0 auto)")
+    ap.add_argument("--spec", type=int, default=1,
+                    help="split kernel: speculative branch-free segments (1, default) or per-symbol votes (0)")
     ap.add_argument("--spare-wave", type=int, default=-1,
                     help="split kernel, idle waves for SIMD balance: -1 auto (default), 0 never, 1 three waves, 2 four")
     return ap.parse_args(argv)
@@ -272,6 +274,7 @@ def rank_main(args):
         ctx.set_option("queue_block", args.queue_block)
     if args.spare_wave >= 0:
         ctx.set_option("spare_wave", args.spare_wave)
+    ctx.set_option("spec", args.spec)
 
     # ---- this rank's bursts of the whole job ---------------------------------------------
     total = args.bursts * world if args.scaling == "weak" else args.bursts

@@ -26,6 +26,7 @@ struct dsp_ctx {
     int batch_split;    // 1 (default): a batch of more tiles than the CUs keep resident goes out as several launches
     int queue_block;    // split kernel: symbols per hand-off block, 0 = automatic
     int lead_copy;      // segment-parallel mode, warm-up rows: 0 = the filter's second store, 1 = seg_lead_copy_k, 2 = filtered per window
+    int spec;           // split kernel, linear interpolator: speculative branch-free segments (1, default) or the per-symbol votes (0)
     int spare_wave;     // split kernel, idle waves for SIMD balance: -1 auto, 0 never, 1 three waves, 2 four waves + CU tickets
     unsigned *cu_tickets;   // [4096] per-CU workgroup counters for the four-wave launch
     unsigned *place;        // diagnostic (option "place_ptr"): caller's device buffer [tiles][2] for the live waves' HW_ID
@@ -242,6 +243,7 @@ int dsp_create(int device_id, dsp_ctx **out)
     c->queue_block = 0;
     c->prio_period = -1;
     c->spare_wave = -1;
+    c->spec = 1;
     c->lead_copy = 0;
     c->fir_stream = 2;
     c->corr_window = 1;
@@ -370,6 +372,8 @@ int dsp_set_option(dsp_ctx *c, const char *name, int64_t value)
     } else if (!strcmp(name, "lead_copy")) {
         if (value < 0 || value > 2) return fail(DSP_E_ARG, "lead_copy must be 0, 1 or 2");
         c->lead_copy = (int)value;
+    } else if (!strcmp(name, "spec")) {
+        c->spec = value != 0;
     } else if (!strcmp(name, "spare_wave")) {
         if (value < -1 || value > 2) return fail(DSP_E_ARG, "spare_wave must be -1 (auto), 0, 1 or 2");
         c->spare_wave = (int)value;
@@ -686,6 +690,25 @@ static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, c
                 if (lds + (size_t)2 * d * 64 * 17 + 16 <= room) { TQ = d; break; }
         }
         while (TQ > 1 && lds + (size_t)2 * TQ * 64 * 17 + 16 > room) TQ--;
+        // Speculative segments (sync_kernels.hip, gardner2 + linear interpolator) end with the DMA block or
+        // the queue block, whichever comes first, and every segment costs a vote and a hand-over: keep the
+        // two block lengths multiples of one another and the shorter one as long as the LDS share allows
+        // (16384 bursts: T 8 / TQ 7 -> segments of 7, 1, 6, 2 ... symbols, 1.03 ms; T 7 / TQ 7: 0.99 ms).
+        if (c->queue_block == 0 && c->spec && P.use_ring && a->variant == DSP_GARDNER2 && P.half_len == 0) {
+            const int rpp = 1024 / (64 * elem);
+            int best_n = 0, best_T = P.T, best_TQ = TQ;
+            for (int tq = TQ; tq >= 1; tq--)
+                for (int t = P.T; t >= 1; t--) {
+                    if ((sps * t) % rpp) continue;                         // whole DMA pieces per block
+                    if (t % tq && tq % t) continue;
+                    const int n = t < tq ? t : tq;
+                    if (n > best_n || (n == best_n && t > best_T)) { best_n = n; best_T = t; best_TQ = tq; }
+                }
+            if (best_n > 0) {
+                TQ = best_TQ;
+                if (best_T != P.T) { P.T = best_T; P.nwait = best_T * n_store_t; }
+            }
+        }
         P.TQ = TQ;
         // From three tiles per CU on two or more waves share a SIMD and the arbiter's oldest-first choice lets
         // some run ahead while others starve; rotating the four priority levels over the wave slots every 8
@@ -698,6 +721,7 @@ static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, c
         P.spare_wave = c->spare_wave >= 0 ? c->spare_wave : (per_cu == 2 && P.half_len == 0 ? 2 : 0);
         P.cu_tickets = c->cu_tickets;
         P.place = c->place;
+        P.spec = c->spec;
         lds += (size_t)2 * TQ * 64 * 17 + 16 + 32;       // + the four-wave launch's five selection words
     }
     if (c->lds_pad >= 0) lds += (size_t)c->lds_pad;

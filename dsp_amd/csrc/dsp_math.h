@@ -265,6 +265,150 @@ DSP_HD FllOut fll_step(const MathK &K, double xr, double xi, double idx, double 
 }
 
 // ---------------------------------------------------------------------------
+// The same iteration restated for instruction-level parallelism (round 3): same values to ~1e-16,
+// a much shorter dependency chain and no wave vote, for the blocks in which every lane of the wave
+// is live.  A lone wave issues a DEPENDENT instruction every ~8 cycles and independent ones every
+// ~5 (tools/ubench/issue_latency.hip), and fll_step above compiles to one serial chain.
+//   * the quadrant index k comes from 4*f*i (= phase * 2/pi up to rounding), formed beside the
+//     phase product instead of after it; pi/2 is taken off in two FMA steps (the third term, k*1.5e-33,
+//     is below 1e-17 for every k that fits the int32 quadrant conversion);
+//   * the quarter turns are applied to the SAMPLE (swap / negate, off the chain) instead of to
+//     (sin, cos): same products, same sums, same bits as rotating by the adjusted pair;
+//   * sin and cos polynomials in Estrin form, interleaved;
+//   * decided = (sign(re) + 1j*sign(im))/sqrt(2) makes sample*conj(decided) = (P + Q) + 1j*sigma*(Q - P)
+//     with P = |re|/sqrt(2), Q = |im|/sqrt(2), sigma = sign(re)*sign(im) -- bit for bit the reference's
+//     four products and two sums (sign changes are exact) as long as neither component is exactly 0
+//     (np.sign(0) = 0 breaks the identity: `zmin` reports min(P, Q) so that the caller can send such
+//     a block to fll_step); the error is then sign * atan(|Q - P| / (P + Q)), first octant by construction;
+//   * second interval of the atan (t >= 7/16): (t - 1)/(t + 1) = -min(P, Q)/max(P, Q), no cancellation;
+//   * reciprocal refined as r0*(1 + e)*(1 + e^2) (error e^4 like two Newton steps, one level less).
+// kmax reports max |4*f*i|: beyond 2^30 the int32 quadrant is wrong (caller: fll_step).
+DSP_HD void sincos_quarter(const MathK &K, double r, double &sn, double &cs)
+{
+    const double z = r * r;
+    const double z2 = z * z;
+    const double rz = r * z;
+    const double hz = fma3(-0.5, z, 1.0);
+    const double s12 = fma3(z, K.v[K_S2], K.v[K_S1]), c12 = fma3(z, K.v[K_C2], K.v[K_C1]);
+    const double s34 = fma3(z, K.v[K_S4], K.v[K_S3]), c34 = fma3(z, K.v[K_C4], K.v[K_C3]);
+    const double s56 = fma3(z, K.v[K_S6], K.v[K_S5]), c56 = fma3(z, K.v[K_C6], K.v[K_C5]);
+    const double sq = fma3(z2, s56, s34), cq = fma3(z2, c56, c34);
+    const double ps = fma3(z2, sq, s12), pc = fma3(z2, cq, c12);
+    sn = fma3(rz, ps, r);
+    cs = fma3(z2, pc, hz);
+}
+
+DSP_HD double div_short(double num, double den)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double r0 = __builtin_amdgcn_rcp(den);
+    const double e = __builtin_fma(-den, r0, 1.0);
+    const double e2 = e * e;
+    const double r1 = __builtin_fma(r0, e, r0);
+    const double r2 = __builtin_fma(r1, e2, r1);
+    const double q = num * r2;
+    const double rem = __builtin_fma(-den, q, num);
+    return __builtin_fma(rem, r2, q);
+#else
+    return num / den;
+#endif
+}
+
+// bit-level helpers of the select-free formulation below.  (Consecutive v_cndmask_b32 in their short
+// encoding -- the compiler's choice for every ?: on a double -- issue at 19 cycles each on gfx950,
+// tools/ubench/issue_latency.hip k_cmp_4cnd_vcc; v_bfi_b32 / v_and_b32 with a computed mask at 4-6.)
+DSP_HD unsigned hi_word(double x) { unsigned long long u; __builtin_memcpy(&u, &x, 8); return (unsigned)(u >> 32); }
+DSP_HD unsigned lo_word(double x) { unsigned long long u; __builtin_memcpy(&u, &x, 8); return (unsigned)u; }
+DSP_HD double from_words(unsigned hi, unsigned lo)
+{
+    unsigned long long u = ((unsigned long long)hi << 32) | lo;
+    double x; __builtin_memcpy(&x, &u, 8);
+    return x;
+}
+// mask ? a : b per bit (mask all ones or all zeros)
+DSP_HD unsigned bsel(unsigned mask, unsigned a, unsigned b) { return (a & mask) | (b & ~mask); }
+DSP_HD double bsel64(unsigned mask, double a, double b)
+{
+    return from_words(bsel(mask, hi_word(a), hi_word(b)), bsel(mask, lo_word(a), lo_word(b)));
+}
+
+// evidence of a block of fll_step_fast calls, kept as integers (high words): no compare, no select
+struct FllEvidence {
+    unsigned zbad;      // max over the block of (hi(P) - 1) and (hi(Q) - 1) as unsigned: >= 0x7fefffff when a
+                        // component was zero (or denormal), infinite or NaN
+    unsigned kmax;      // max over the block of hi(|4*f*i|): >= hi(2^30) when the int32 quadrant is unsafe
+};
+DSP_HD void fll_evidence_init(FllEvidence &e) { e.zbad = 0u; e.kmax = 0u; }
+DSP_HD bool fll_evidence_bad(const FllEvidence &e) { return e.zbad >= 0x7fefffffu || e.kmax >= 0x41d00000u; }
+
+DSP_HD FllOut fll_step_fast(const MathK &K, double xr, double xi, double idx, double idx4, double &curr_freq,
+                            double &integrator, double kp, double ki, FllEvidence &ev)
+{
+    const double t1 = K.v[K_TWO_PI] * curr_freq;
+    const double kq = curr_freq * idx4;
+    const double phase = t1 * idx;                      // :16, the reference's two roundings
+    const double k = d_rint(kq);
+    double r = fma3(-k, K.v[K_P1], phase);
+    r = fma3(-k, K.v[K_P2], r);
+    const unsigned kh = hi_word(kq) & 0x7fffffffu;
+    ev.kmax = kh > ev.kmax ? kh : ev.kmax;
+    // x * (-1j)^k, off the chain
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int q = __double2int_rz(k);
+#else
+    const int q = (int)(long long)k;
+#endif
+    const unsigned odd = 0u - ((unsigned)q & 1u);       // all ones when k is odd
+    const unsigned neg_r = ((unsigned)q << 30) & 0x80000000u;
+    const unsigned neg_i = (((unsigned)q + 1u) << 30) & 0x80000000u;
+    const double ar = from_words(bsel(odd, hi_word(xi), hi_word(xr)) ^ neg_r, bsel(odd, lo_word(xi), lo_word(xr)));
+    const double ai = from_words(bsel(odd, hi_word(xr), hi_word(xi)) ^ neg_i, bsel(odd, lo_word(xr), lo_word(xi)));
+    double sn, cs;
+    sincos_quarter(K, r, sn, cs);
+    const double sr = ar * cs + ai * sn;                // :17
+    const double si = ai * cs - ar * sn;
+    const double P = d_abs(sr) * K.v[K_SCL], Q = d_abs(si) * K.v[K_SCL];
+    const double S = P + Q, D = Q - P;                  // :21: re and sigma * im of sample * conj(decided)
+    const double mn = __builtin_fmin(P, Q), mx = __builtin_fmax(P, Q);
+    const unsigned zp = hi_word(P) - 1u, zq = hi_word(Q) - 1u;
+    const unsigned zpq = zp > zq ? zp : zq;
+    ev.zbad = zpq > ev.zbad ? zpq : ev.zbad;
+    const double aD = d_abs(D);
+    // second interval (t >= 7/16) <=> 7*S - 16*|D| < 0; at equality either interval serves
+    const double c2d = fma3(-16.0, aD, 7.0 * S);
+    const unsigned c2 = (unsigned)((int)hi_word(c2d) >> 31);
+    const double num = bsel64(c2, -mn, aD);
+    const double den = bsel64(c2, mx, S);
+    const double hi = from_words(hi_word(K.v[K_PIO4_HI]) & c2, lo_word(K.v[K_PIO4_HI]) & c2);
+    const double lo = from_words(hi_word(K.v[K_PIO4_LO]) & c2, lo_word(K.v[K_PIO4_LO]) & c2);
+#ifdef DSP_EXP_FLL_CHEAP          // experiment: which wave is the bottleneck (results are wrong)
+    const double t = num * den;
+#else
+    const double t = div_short(num, den);
+#endif
+    const double z = t * t;
+    const double w = z * z;
+    const double w2 = w * w;
+    const double e0 = fma3(w, K.v[K_AT2], K.v[K_AT0]), f0 = fma3(w, K.v[K_AT3], K.v[K_AT1]);
+    const double e1 = fma3(w, K.v[K_AT6], K.v[K_AT4]), f1 = fma3(w, K.v[K_AT7], K.v[K_AT5]);
+    const double e2 = fma3(w, K.v[K_AT10], K.v[K_AT8]);
+    const double s1 = z * fma3(w2, fma3(w2, e2, e1), e0);
+    const double s2 = w * fma3(w2, fma3(w2, K.v[K_AT9], f1), f0);
+    const double a = hi - ((t * (s1 + s2) - lo) - t);
+    // sign of sigma * (Q - P)
+    const double error = from_words(hi_word(a) ^ ((hi_word(sr) ^ hi_word(si) ^ hi_word(D)) & 0x80000000u), lo_word(a));
+    integrator += error * ki;                           // :22
+    const double ef_n = error * kp + integrator;        // :23
+    curr_freq += ef_n;                                  // :25
+    FllOut o;
+    o.sr = sr; o.si = si; o.ef = ef_n; o.freq = curr_freq;
+    // (Re < 0) + 2 (Im < 0) from the sign bits: exact for every sample the evidence lets through
+    // (-0 and NaN, where the sign bit and the comparison disagree, send the block to fll_step)
+    o.quad = (int)((hi_word(sr) >> 31) | ((hi_word(si) >> 30) & 2u));
+    return o;
+}
+
+// ---------------------------------------------------------------------------
 // Linear interpolation sig[i]*(1-frac) + sig[i+1]*frac with the reference's
 // rounding (gardner2.py:47-48, hw1/gardner.py:19).
 DSP_HD cd lerp(cd a, cd b, double frac)

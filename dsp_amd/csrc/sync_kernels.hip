@@ -48,6 +48,11 @@ __device__ __forceinline__ void lds_dma_16B(const void *g, unsigned lds_off)
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                  :: "v"(g), "s"(lds_off) : "memory", "m0");
 }
+__device__ __forceinline__ void lds_dma_pair(const void *g, unsigned lds_off)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024"
+                 :: "v"(g), "s"(lds_off) : "memory", "m0");
+}
 // n (1..4) consecutive 1 KiB pieces with one M0 / one address: the instruction offset moves
 // the global and the LDS address together
 __device__ __forceinline__ void lds_dma_group(const void *g, unsigned lds_off, int n)
@@ -102,12 +107,18 @@ __device__ __forceinline__ void st_cplx(d2v *p, double re, double im, bool keep 
 // 5 wait states of a VALU write to it.  The compiler keeps that distance for its own instructions but
 // cannot see inside asm text, and under register pressure it restores a spilled base with
 // `v_readlane_b32 s1, v127, 37` DIRECTLY in front of the asm: the store then goes through a
-// half-restored 64-bit address.  The guard is therefore part of the asm text: the base is copied by a
-// SALU move into a scalar temporary of the asm's own (SALU reads of VALU-written SGPRs are interlocked,
-// and a VMEM read of a SALU-written SGPR needs no wait), or -- DSP_SST_GUARD 2 -- five wait states are
-// spent in front of the store.  tools/isa_lint.py checks every build flavour's assembly for the rule.
+// half-restored 64-bit address.  The guard is therefore part of the asm text: five wait states in front
+// of the store (DSP_SST_GUARD 2, the default), or -- 1 -- a SALU copy of the base into a scalar temporary
+// of the asm's own (SALU reads of VALU-written SGPRs are interlocked, a VMEM read of a SALU-written SGPR
+// needs no wait).  Measured at B = 65536 / 32768 with one guard per store: copy +0.5 % / +1.9 %, wait
+// states +1.0 % / +4.2 % (profiles/r03_sst_guard_ab.txt).  The copy is cheaper, but the compiler may hand
+// the asm a temporary that a VALU instruction wrote a few instructions earlier (a dead v_readlane target):
+// harmless as far as the ISA text goes, yet outside the rule LLVM itself applies (ANY VALU write of the
+// register inside the window counts), which is the rule tools/isa_lint.py enforces on every build
+// flavour.  The hot paths group their stores behind ONE wait (GroupStore below), so the default is the
+// form that needs no argument.
 #ifndef DSP_SST_GUARD
-#define DSP_SST_GUARD 1
+#define DSP_SST_GUARD 2
 #endif
 #if DSP_SST_GUARD == 1
 #define DSP_SST(OPC, TAIL)                                                                          \
@@ -127,21 +138,94 @@ __device__ __forceinline__ void sst(const void *base, unsigned voff, d2v v) { DS
 __device__ __forceinline__ void sst_b8(const void *base, unsigned voff, unsigned v) { DSP_SST("global_store_byte", ""); }
 #undef DSP_SST
 
-#define WCASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+// Several stores through wave-uniform bases in ONE asm statement: every base is an input of the
+// statement, so whatever restores the compiler needs sit in front of it, and the five wait states
+// are spent once for the group.  (One statement per store with its own guard costs the timing wave
+// 2 % at B <= 32768: four extra instructions per symbol on a lone wave.)
+// Operand order: [voff_c, cplx, base_c,] voff_s, s0, base0 [, s1, base1 [, s2, base2]]; dec: voff_b, byte, base.
+template <typename OC> struct GroupStore;
+#define DSP_GS_IMPL(OC_T, OS_T, OCOP, OSOP, PAD)                                                                  \
+    template <> struct GroupStore<OC_T> {                                                                         \
+        static __device__ __forceinline__ void c_s_s(unsigned oc, OC_T c, const void *bc, unsigned os, OS_T a,   \
+                                                     const void *ba, OS_T b, const void *bb)                    \
+        {                                                                                                         \
+            asm volatile("s_nop 4\n\t" OCOP " %0, %1, %2\n\t" OSOP " %3, %4, %5\n\t" OSOP " %3, %6, %7" PAD        \
+                         :: "v"(oc), "v"(c), "s"(bc), "v"(os), "v"(a), "s"(ba), "v"(b), "s"(bb) : "memory");      \
+        }                                                                                                         \
+        static __device__ __forceinline__ void c_s_s_s(unsigned oc, OC_T c, const void *bc, unsigned os, OS_T a, \
+                                                       const void *ba, OS_T b, const void *bb, OS_T d,          \
+                                                       const void *bd)                                           \
+        {                                                                                                         \
+            asm volatile("s_nop 4\n\t" OCOP " %0, %1, %2\n\t" OSOP " %3, %4, %5\n\t" OSOP " %3, %6, %7\n\t"        \
+                         OSOP " %3, %8, %9" PAD                                                                    \
+                         :: "v"(oc), "v"(c), "s"(bc), "v"(os), "v"(a), "s"(ba), "v"(b), "s"(bb), "v"(d), "s"(bd)  \
+                         : "memory");                                                                             \
+        }                                                                                                         \
+        static __device__ __forceinline__ void s_s(unsigned os, OS_T a, const void *ba, OS_T b, const void *bb)  \
+        {                                                                                                         \
+            asm volatile("s_nop 4\n\t" OSOP " %0, %1, %2\n\t" OSOP " %0, %3, %4"                                   \
+                         :: "v"(os), "v"(a), "s"(ba), "v"(b), "s"(bb) : "memory");                                \
+        }                                                                                                         \
+        static __device__ __forceinline__ void s(unsigned os, OS_T a, const void *ba)                            \
+        {                                                                                                         \
+            asm volatile("s_nop 4\n\t" OSOP " %0, %1, %2" :: "v"(os), "v"(a), "s"(ba) : "memory");                \
+        }                                                                                                         \
+        static __device__ __forceinline__ void c_s_s_b(unsigned oc, OC_T c, const void *bc, unsigned os, OS_T a, \
+                                                       const void *ba, OS_T b, const void *bb, unsigned ob,     \
+                                                       unsigned q, const void *bq)                               \
+        {                                                                                                         \
+            asm volatile("s_nop 4\n\t" OCOP " %0, %1, %2\n\t" OSOP " %3, %4, %5\n\t" OSOP " %3, %6, %7\n\t"        \
+                         "global_store_byte %8, %9, %10" PAD                                                       \
+                         :: "v"(oc), "v"(c), "s"(bc), "v"(os), "v"(a), "s"(ba), "v"(b), "s"(bb), "v"(ob), "v"(q), \
+                            "s"(bq) : "memory");                                                                  \
+        }                                                                                                         \
+        static __device__ __forceinline__ void s_b(unsigned os, OS_T a, const void *ba, unsigned ob, unsigned q, \
+                                                   const void *bq)                                               \
+        {                                                                                                         \
+            asm volatile("s_nop 4\n\t" OSOP " %0, %1, %2\n\tglobal_store_byte %3, %4, %5"                         \
+                         :: "v"(os), "v"(a), "s"(ba), "v"(ob), "v"(q), "s"(bq) : "memory");                       \
+        }                                                                                                         \
+        static __device__ __forceinline__ void b(unsigned ob, unsigned q, const void *bq)                        \
+        {                                                                                                         \
+            asm volatile("s_nop 4\n\tglobal_store_byte %0, %1, %2" :: "v"(ob), "v"(q), "s"(bq) : "memory");       \
+        }                                                                                                         \
+    }
+DSP_GS_IMPL(f2v, float, "global_store_dwordx2", "global_store_dword", "");
+DSP_GS_IMPL(d2v, double, "global_store_dwordx4", "global_store_dwordx2", DSP_WIDE_STORE_PAD);
+#undef DSP_GS_IMPL
+
+template <typename T>
+__device__ __forceinline__ T lds_ld(unsigned byte_addr)
+{
+    return *(const __attribute__((address_space(3))) T *)byte_addr;
+}
+template <typename T>
+__device__ __forceinline__ void lds_st(unsigned byte_addr, T v)
+{
+    *(__attribute__((address_space(3))) T *)byte_addr = v;
+}
+
+// s_waitcnt takes its count as an immediate; the count here is a per-launch constant (stores issued per
+// DMA block).  A switch over 64 cases compiles to a tree of ~25 scalar branches that a lone wave walks at
+// ~20 cycles each, once per DMA block (measured: 200 cycles per SYMBOL went into advance()).  The host
+// therefore rounds the count DOWN to a multiple of four above 8 (waiting for a few more of the block's
+// oldest stores: stricter, never laxer) and the kernel decides in at most five uniform branches.
+#define WV(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 __device__ __forceinline__ void wait_vmcnt(int n)
 {
-    switch (n) {
-        WCASE(1) WCASE(2) WCASE(3) WCASE(4) WCASE(5) WCASE(6) WCASE(7) WCASE(8)
-        WCASE(9) WCASE(10) WCASE(11) WCASE(12) WCASE(13) WCASE(14) WCASE(15) WCASE(16)
-        WCASE(17) WCASE(18) WCASE(19) WCASE(20) WCASE(21) WCASE(22) WCASE(23) WCASE(24)
-        WCASE(25) WCASE(26) WCASE(27) WCASE(28) WCASE(29) WCASE(30) WCASE(31) WCASE(32)
-        WCASE(33) WCASE(34) WCASE(35) WCASE(36) WCASE(37) WCASE(38) WCASE(39) WCASE(40)
-        WCASE(41) WCASE(42) WCASE(43) WCASE(44) WCASE(45) WCASE(46) WCASE(47) WCASE(48)
-        WCASE(49) WCASE(50) WCASE(51) WCASE(52) WCASE(53) WCASE(54) WCASE(55) WCASE(56)
-        WCASE(57) WCASE(58) WCASE(59) WCASE(60) WCASE(61) WCASE(62) WCASE(63)
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    if (n >= 32) {
+        if (n >= 48) { if (n >= 56) { if (n >= 60) WV(60); else WV(56); } else { if (n >= 52) WV(52); else WV(48); } }
+        else { if (n >= 40) { if (n >= 44) WV(44); else WV(40); } else { if (n >= 36) WV(36); else WV(32); } }
+    } else if (n >= 16) {
+        if (n >= 24) { if (n >= 28) WV(28); else WV(24); } else { if (n >= 20) WV(20); else WV(16); }
+    } else if (n >= 8) {
+        if (n >= 12) WV(12); else WV(8);
+    } else {
+        if (n >= 4) { if (n >= 6) { if (n >= 7) WV(7); else WV(6); } else { if (n >= 5) WV(5); else WV(4); } }
+        else { if (n >= 2) { if (n >= 3) WV(3); else WV(2); } else { if (n >= 1) WV(1); else WV(0); } }
     }
 }
+#undef WV
 
 // transcendental constants: loaded once per lane through an opaque index so that they
 // stay in VGPRs (see dsp_math.h)
@@ -200,21 +284,24 @@ struct Tile {
         z.im = SC ? (double)v.y * scale : (double)v.y;
         return z;
     }
-    // issue the DMA pieces for rows [F, F_new): groups of up to four 1 KiB pieces that do not
-    // cross a 4 KiB boundary of the ring (so never its wrap) share one M0 and one address
+    // issue the DMA pieces for rows [F, F_new).  Blocks are whole numbers of 1 KiB pieces and the ring is a
+    // power of two of them, so PAIRS of pieces that start on an even piece never cross the ring's end: two
+    // pieces per M0 / address, one uniform loop without a switch (the four-piece groups of rounds 1-2 cost a
+    // four-way branch per group and the same number of VMEM instructions).
     __device__ __forceinline__ void issue(int F_new)
     {
         constexpr int RPP = InT<IN>::RPP;
         F_new = F_new < in_rows ? F_new : in_rows;
         int r = F;
-        while (r < F_new) {
-            int g = 4 - ((r / RPP) & 3);
-            const int left = (F_new - r + RPP - 1) / RPP;
-            g = g < left ? g : left;
-            const unsigned char *gp = (const unsigned char *)(xt + (size_t)r * 64) + lane * 16;
-            lds_dma_group(gp, lds_base + (unsigned)((r & RM) * 64 * (int)sizeof(IN)), g);
-            r += g * RPP;
+        const unsigned char *gp = (const unsigned char *)(xt + (size_t)r * 64) + lane * 16;
+        if (r < F_new && ((r / RPP) & 1)) {              // an odd first piece goes alone
+            lds_dma_16B(gp, lds_base + (unsigned)((r & RM) * 64 * (int)sizeof(IN)));
+            r += RPP; gp += 1024;
         }
+        for (; r + 2 * RPP <= F_new; r += 2 * RPP, gp += 2048)
+            lds_dma_pair(gp, lds_base + (unsigned)((r & RM) * 64 * (int)sizeof(IN)));
+        for (; r < F_new; r += RPP, gp += 1024)          // (a last piece, whole or -- at the tile's end -- partial)
+            lds_dma_16B(gp, lds_base + (unsigned)((r & RM) * 64 * (int)sizeof(IN)));
         F = F_new > F ? F_new : F;
     }
     // start of DMA block `blk` (T iterations of `step` rows each)
@@ -390,6 +477,202 @@ __device__ __forceinline__ bool g2_steady(const Tile<IN> &tl, dspm::GState &gs, 
     pos = i_o;
     gs.mu = mu_n;
     gs.k += tc.sps;                                      // :98
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// Speculative steady segment (round 3): n consecutive gardner2.py iterations as ONE branch-free
+// instruction stream, checked once at its end.
+//
+// A lone wave issues a dependent instruction every ~8 cycles, an independent one every ~5, and a wave
+// vote (v_cmp -> s_cmp -> s_cbranch) stalls it for ~58: g2_steady above pays two votes per symbol and
+// its branches cut the symbol into basic blocks the scheduler cannot overlap.  Here nothing inside the
+// segment depends on a vote.  Every lane assumes what is true of a locked loop -- mu inside
+// [-sps, sps), the three instants in one binade (then idx_mid = idx_early + sps/2 and idx_late =
+// idx_early + sps hold EXACTLY, so one truncation and one fraction serve all three), the rows inside
+// the ring window, |alpha * e| < 1 (then the output instant lies within one sample of the late one) --
+// and records the evidence in four accumulators.  One vote at the end of the segment; if any lane's
+// assumption failed, the caller restores (mu, k) and runs the same symbols through the per-symbol code,
+// whose stores and queue entries overwrite the segment's.  Values are those of g2_steady bit for bit
+// (same products and sums in the same order).
+//   * the output sample (k + mu_new) is fetched by per-lane address one symbol late: its LDS latency and
+//     its conversions fall into the next symbol's chain instead of extending this one;
+//   * stores go out as one guarded group per symbol (GroupStore); MASK = the outputs present
+//     (1 rec, 2 err, 4 mu, 8 pos), -1 = decided at run time per store.
+struct SpecBases { const unsigned char *rec_t, *err_t, *mu_t, *pos_t; };
+
+template <typename IN, bool SC>
+__device__ __forceinline__ cd widen(const IN v, const double scale)
+{
+    cd z;
+    z.re = SC ? (double)v.x * scale : (double)v.x;
+    z.im = SC ? (double)v.y * scale : (double)v.y;
+    return z;
+}
+
+// lt ? a : (gt ? b : c), bit by bit through masks (see dsp_math.h on v_cndmask)
+__device__ __forceinline__ f2v pick3(unsigned lt, unsigned gt, f2v a, f2v b, f2v c)
+{
+    f2v r;
+    r.x = __uint_as_float(dspm::bsel(lt, __float_as_uint(a.x), dspm::bsel(gt, __float_as_uint(b.x), __float_as_uint(c.x))));
+    r.y = __uint_as_float(dspm::bsel(lt, __float_as_uint(a.y), dspm::bsel(gt, __float_as_uint(b.y), __float_as_uint(c.y))));
+    return r;
+}
+__device__ __forceinline__ d2v pick3(unsigned lt, unsigned gt, d2v a, d2v b, d2v c)
+{
+    d2v r;
+    r.x = dspm::bsel64(lt, a.x, dspm::bsel64(gt, b.x, c.x));
+    r.y = dspm::bsel64(lt, a.y, dspm::bsel64(gt, b.y, c.y));
+    return r;
+}
+
+template <typename IN, bool SC, int MASK>
+__device__ __forceinline__ bool g2_spec_segment(const Tile<IN> &tl, dspm::GState &gs, const TimingConst &tc,
+                                                const int n, const int it0, const int roff, const SpecBases &sb,
+                                                const unsigned lane_s, const unsigned lane_c, const unsigned q_addr)
+{
+    typedef typename InT<IN>::OS OS;
+    typedef typename InT<IN>::OC OC;
+    typedef GroupStore<OC> GS;
+    constexpr unsigned ROWB = 64u * (unsigned)sizeof(IN);
+    const unsigned rmask = (unsigned)tl.R * ROWB - 1u;
+    // (the caller has checked that the ring starts on a multiple of its size: row bits, column bits and
+    //  base bits do not overlap, so one v_and_or forms an address)
+    const unsigned colb = tl.lds_base + (unsigned)tl.col * (unsigned)sizeof(IN);
+    const double alpha = tc.alpha, spsd = tc.spsd, scale = tl.scale;
+    const int win_lo = tl.win_lo;
+    const int wlim = tl.win_hi - win_lo - (tc.sps + 3);  // rows r_a .. r_a + sps + 2 inside [win_lo, win_hi)
+    const unsigned midb = (unsigned)(tc.sps / 2) * ROWB, lateb = (unsigned)tc.sps * ROWB;   // :74 integer half
+    double mu = gs.mu;
+    double kd = (double)gs.k, kd4 = kd - spsd;
+    unsigned acc_x = 0u, acc_w = 0u, acc_mu = 0u, acc_e = 0u;
+    unsigned row_s = (unsigned)it0 * 64u * (unsigned)sizeof(OS) + lane_s;
+    unsigned row_c = (unsigned)(it0 + roff) * 64u * (unsigned)sizeof(OC) + lane_c;
+    unsigned qa = q_addr;
+    const unsigned mu_lim = (unsigned)__double2hiint(spsd);     // |mu| < sps <=> hi(|mu|) < hi(sps): sps is a small integer
+    IN e0, e1, m0, m1, lm, l0, l1, l2;                   // rows early, early+1, mid, mid+1, late-1 .. late+2
+    double i_a = 0.0;
+    int r_c = 0;
+    unsigned ev_mu = 0u;                                 // the evidence of the symbol whose rows are in flight
+    unsigned hi_c = 0u, w_cur = 0u;
+
+    auto issue = [&]() {                                 // indices, evidence, the eight row loads
+        i_a = kd4 + mu;                                  // gardner2.py:73
+        const double i_c = kd + mu;                      // :75
+        const int r_a = __double2int_rz(i_a);
+        r_c = r_a + tc.sps;
+        hi_c = (unsigned)__double2hiint(i_c);
+        w_cur = (unsigned)(r_a - win_lo);
+        ev_mu = (unsigned)__double2hiint(mu) & 0x7fffffffu;                // NaN counts as too large
+        const unsigned rb = (unsigned)r_a * ROWB;
+        e0 = lds_ld<IN>((rb & rmask) | colb);
+        e1 = lds_ld<IN>(((rb + ROWB) & rmask) | colb);
+        m0 = lds_ld<IN>(((rb + midb) & rmask) | colb);
+        m1 = lds_ld<IN>(((rb + midb + ROWB) & rmask) | colb);
+        lm = lds_ld<IN>(((rb + lateb - ROWB) & rmask) | colb);
+        l0 = lds_ld<IN>(((rb + lateb) & rmask) | colb);
+        l1 = lds_ld<IN>(((rb + lateb + ROWB) & rmask) | colb);
+        l2 = lds_ld<IN>(((rb + lateb + 2u * ROWB) & rmask) | colb);
+    };
+
+    issue();
+    // The instants grow from symbol to symbol (k by sps, mu by less than one sample -- acc_e), so the
+    // binade and the window have to be looked at for the first and the last symbol only.
+    const unsigned hi_first = (unsigned)__double2hiint(i_a);
+    acc_w = w_cur;
+    unsigned hi_last = 0u, w_last = 0u;
+    for (int s = 0; s < n; s++) {
+        // ---- TED and loop update (the loop-carried chain) ----
+        hi_last = hi_c; w_last = w_cur;
+        acc_mu = ev_mu > acc_mu ? ev_mu : acc_mu;
+        const double f = dspm::fract_pos(i_a);           // == fract(idx_mid) == fract(idx_late), see above
+        const cd xa = dspm::lerp(widen<IN, SC>(e0, scale), widen<IN, SC>(e1, scale), f);
+        const cd xb = dspm::lerp(widen<IN, SC>(m0, scale), widen<IN, SC>(m1, scale), f);
+        const cd xc = dspm::lerp(widen<IN, SC>(l0, scale), widen<IN, SC>(l1, scale), f);
+        const double e = dspm::ted_error(xa, xb, xc);    // :87
+        const double ae = alpha * e;
+        const double mu_n = mu - ae;                     // :91
+        const unsigned ah = (unsigned)__double2hiint(ae) & 0x7fffffffu;
+        acc_e = ah > acc_e ? ah : acc_e;
+        const double i_o = kd + mu_n;                    // :95
+        // |alpha*e| < 1: the output instant lies within one sample of the late one, so its two samples
+        // are among the four rows around it -- a per-lane select on the raw rows, no second LDS trip
+        const int d = __double2int_rz(i_o) - r_c;
+        const unsigned m_lt = (unsigned)(d >> 31), m_gt = (unsigned)((0 - d) >> 31);    // all ones: d < 0 / d > 0
+        const IN o0 = pick3(m_lt, m_gt, lm, l1, l0);
+        const IN o1 = pick3(m_lt, m_gt, l0, l2, l1);
+        const double fo = dspm::fract_pos(i_o);
+        mu = mu_n;
+        kd += spsd; kd4 += spsd;                         // :98
+        // ---- the next symbol's rows fly while this one's outputs are formed ----
+        issue();
+        const cd rec = dspm::lerp(widen<IN, SC>(o0, scale), widen<IN, SC>(o1, scale), fo);
+        const OC rv = {(OS)rec.re, (OS)rec.im};
+        if (MASK == 7) GS::c_s_s(row_c, rv, sb.rec_t, row_s, (OS)e, sb.err_t, (OS)mu_n, sb.mu_t);
+        else if (MASK == 15) GS::c_s_s_s(row_c, rv, sb.rec_t, row_s, (OS)e, sb.err_t, (OS)mu_n, sb.mu_t, (OS)i_o, sb.pos_t);
+        else if (MASK == 12) GS::s_s(row_s, (OS)mu_n, sb.mu_t, (OS)i_o, sb.pos_t);
+        else if (MASK == 4) GS::s(row_s, (OS)mu_n, sb.mu_t);
+        else if (MASK != 0) {
+            if (sb.rec_t) sst(sb.rec_t, row_c, rv);
+            if (sb.err_t) sst(sb.err_t, row_s, (OS)e);
+            if (sb.mu_t) sst(sb.mu_t, row_s, (OS)mu_n);
+            if (sb.pos_t) sst(sb.pos_t, row_s, (OS)i_o);
+        }
+        const d2v qv = {rec.re, rec.im};
+        lds_st<d2v>(qa, qv);
+        row_s += 64u * (unsigned)sizeof(OS); row_c += 64u * (unsigned)sizeof(OC); qa += 1024u;
+    }
+    // (the rows issued for symbol n are read and dropped: ring addresses are always valid)
+    acc_x = hi_first ^ hi_last;
+    acc_w = w_last > acc_w ? w_last : acc_w;
+    const bool bad = (acc_x >> 20) != 0u || acc_w > (unsigned)wlim || acc_mu >= mu_lim || acc_e >= 0x3ff00000u;
+    if (__any(bad)) return false;
+    gs.mu = mu;
+    gs.k += tc.sps * n;
+    return true;
+}
+
+// The FLL wave's side of it: a queue block whose symbols all came from speculative segments (every lane
+// produced every symbol) through fll_step_fast, one vote at the end (a derotated sample with a component
+// exactly zero, a quadrant index beyond int32: the caller then runs the block through fll_step from the
+// saved state).  MASK: 1 sig, 2 freq, 4 ef, 8 dec; -1 = decided at run time per store.
+struct SpecBasesF { const unsigned char *sig_t, *freq_t, *ef_t, *dec_t; };
+
+template <typename OS, typename OC, int MASK>
+__device__ __forceinline__ bool fll_spec_block(const dspm::MathK &MK, const int n, const unsigned q_addr, const d2v x0, const int row0,
+                                               const double i0, double &freq, double &integ, const double kp,
+                                               const double ki, const SpecBasesF &sb, const unsigned lane)
+{
+    typedef GroupStore<OC> GS;
+    double f = freq, g = integ;
+    dspm::FllEvidence ev;
+    dspm::fll_evidence_init(ev);
+    double idx = (double)row0 + i0, idx4 = 4.0 * idx;
+    unsigned off_c = (unsigned)row0 * 64u * (unsigned)sizeof(OC) + lane * (unsigned)sizeof(OC);
+    unsigned off_s = (unsigned)row0 * 64u * (unsigned)sizeof(OS) + lane * (unsigned)sizeof(OS);
+    unsigned off_b = (unsigned)row0 * 64u + lane;
+    unsigned qa = q_addr;
+    d2v x = x0;                                          // the block's first sample, read beside the block's flags
+    for (int t = 0; t < n; t++) {
+        qa += 1024u;
+        const d2v xn = lds_ld<d2v>(qa);                  // next symbol's sample (behind the block: read, not used)
+        const dspm::FllOut o = dspm::fll_step_fast(MK, x.x, x.y, idx, idx4, f, g, kp, ki, ev);
+        const OC sv = {(OS)o.sr, (OS)o.si};
+        if (MASK == 15) GS::c_s_s_b(off_c, sv, sb.sig_t, off_s, (OS)o.freq, sb.freq_t, (OS)o.ef, sb.ef_t, off_b, (unsigned)o.quad, sb.dec_t);
+        else if (MASK == 10) GS::s_b(off_s, (OS)o.freq, sb.freq_t, off_b, (unsigned)o.quad, sb.dec_t);
+        else if (MASK == 8) GS::b(off_b, (unsigned)o.quad, sb.dec_t);
+        else if (MASK != 0) {
+            if (sb.sig_t) sst(sb.sig_t, off_c, sv);
+            if (sb.freq_t) sst(sb.freq_t, off_s, (OS)o.freq);
+            if (sb.ef_t) sst(sb.ef_t, off_s, (OS)o.ef);
+            if (sb.dec_t) sst_b8(sb.dec_t, off_b, (unsigned)o.quad);
+        }
+        idx += 1.0; idx4 += 4.0;
+        off_c += 64u * (unsigned)sizeof(OC); off_s += 64u * (unsigned)sizeof(OS); off_b += 64u;
+        x = xn;
+    }
+    if (__any(dspm::fll_evidence_bad(ev))) return false;
+    freq = f; integ = g;
     return true;
 }
 
@@ -791,6 +1074,14 @@ __global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
     }
     const unsigned slot = wave_slot();
     int prio_n = P.prio_period, prio_c = 1, prio_ph = 0;
+    // coarse timers of the trace build, kept in registers (the stamps build's TrAcc lives in scratch memory
+    // and every stamp waits for vmcnt(0): with LDS-DMA in flight that measures the DMA, not the code)
+#if defined(DSP_TRACE) && !defined(DSP_TRACE_STAMPS)
+    unsigned long long tt_last = __builtin_amdgcn_s_memtime(), tt_a = 0, tt_b = 0, tt_c = 0, tt_d = 0, tt_e = 0, tt_f = 0;
+#define DSP_TT(acc) do { const unsigned long long tt_now = __builtin_amdgcn_s_memtime(); acc += tt_now - tt_last; tt_last = tt_now; } while (0)
+#else
+#define DSP_TT(acc) ((void)0)
+#endif
 #ifdef DSP_TRACE
     const unsigned long long tr_t0 = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -841,13 +1132,25 @@ __global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
         const unsigned char *pos_t = (const unsigned char *)(o_pos + (size_t)tile * out_rows * 64);
         const unsigned lane_s = lane * (unsigned)sizeof(OS), lane_c = lane * (unsigned)sizeof(OC);
         int n_steady = 0;
+        // speculative segments (g2_spec_segment): gardner2 with the linear interpolator, ring in use and
+        // starting on a multiple of its size
+        constexpr bool SPEC = (VARIANT == DSP_VARIANT_GARDNER2 && H == 0);
+        const int tmask = (o_rec ? 1 : 0) | (o_terr ? 2 : 0) | (o_mu ? 4 : 0) | (o_pos ? 8 : 0);
+        const bool spec_cfg = SPEC && ring && P.spec != 0 &&
+                              (tl.lds_base & ((unsigned)tl.R * 64u * (unsigned)sizeof(IN) - 1u)) == 0u;
+        const SpecBases sbases = {o_rec ? rec_t : nullptr, o_terr ? err_t : nullptr, o_mu ? mu_t : nullptr,
+                                  o_pos ? pos_t : nullptr};
+        const unsigned q_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)q_base + (unsigned)lane * 16u;
+        bool qb_spec = true;          // every symbol of the current queue block came from a speculative segment
         // DMA blocks (T iterations) and queue blocks (TQ iterations) tick independently
         int it = 0, tq = 0, buf = 0;
         bool more = true;
         for (int blk = 0; more; blk++) {
             if (prio_n && --prio_c == 0) { prio_c = prio_n; rotate_priority(slot, ++prio_ph); }
             DSP_TR(trp, 0);
+            DSP_TT(tt_d);
             if (ring) tl.advance(blk, sps, T, P.C, P.nwait);
+            DSP_TT(tt_a);
             DSP_TR(trp, 9);
             // the steady path's stores address a row by a 32-bit byte offset from the tile's base: a
             // block whose last row would pass 4 GiB (row 2^22 of a complex128 output) takes the
@@ -855,55 +1158,90 @@ __global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
             bool steady = steady_ok && all_active && tl.win_lo > 0 && tl.win_hi + 2 * sps + 1 <= min_len &&
                           it + T + ROFF < cap_rows &&
                           (unsigned long long)(it + T + ROFF + 1) * 64ull * sizeof(OC) <= 0xffffffffull;
-            for (int t = 0; t < T; t++, it++) {
-                DSP_TR(trp, 0);
-                bool done = false;
-                if (steady) {
-                    cd rec; double e, ps;
-                    if constexpr (H > 0) done = g2_steady_lagr<IN, SC, H>(tl, gs, tc, Lp, rec, e, ps);
-                    else done = g2_steady<IN, SC>(tl, gs, tc, rec, e, ps);
-                    if (done) {
-                        DSP_TR(trp, 5);
-                        const unsigned row_s = (unsigned)it * 64u * (unsigned)sizeof(OS);
-                        const unsigned row_c = (unsigned)(it + ROFF) * 64u * (unsigned)sizeof(OC);
-                        OC rv = {(OS)rec.re, (OS)rec.im};
-                        if (o_rec) sst(rec_t, lane_c + row_c, rv);
-                        if (o_terr) sst(err_t, lane_s + row_s, (OS)e);
-                        if (o_mu) sst(mu_t, lane_s + row_s, (OS)gs.mu);
-                        if (o_pos) sst(pos_t, lane_s + row_s, (OS)ps);
-                        DSP_TR(trp, 6);
-                        d2v qv = {rec.re, rec.im};
-                        q_data[(buf * TQ + tq) * 64 + lane] = qv;
-                        q_flag[(buf * TQ + tq) * 64 + lane] = 1;
-                        n_steady++;
+            int t = 0;
+            while (t < T) {
+                // a segment ends with the DMA block or the queue block, whichever comes first
+                const int n = T - t < TQ - tq ? T - t : TQ - tq;
+                bool seg_done = false;
+                if (SPEC && steady && spec_cfg && tl.win_hi - tl.win_lo >= sps + 3) {
+                    const unsigned qa = q_lds + (unsigned)(buf * TQ + tq) * 1024u;
+                    DSP_TR(trp, 10);
+                    DSP_TT(tt_e);
+                    switch (tmask) {
+                        case 7: seg_done = g2_spec_segment<IN, SC, 7>(tl, gs, tc, n, it, ROFF, sbases, lane_s, lane_c, qa); break;
+                        case 15: seg_done = g2_spec_segment<IN, SC, 15>(tl, gs, tc, n, it, ROFF, sbases, lane_s, lane_c, qa); break;
+                        case 12: seg_done = g2_spec_segment<IN, SC, 12>(tl, gs, tc, n, it, ROFF, sbases, lane_s, lane_c, qa); break;
+                        case 4: seg_done = g2_spec_segment<IN, SC, 4>(tl, gs, tc, n, it, ROFF, sbases, lane_s, lane_c, qa); break;
+                        case 0: seg_done = g2_spec_segment<IN, SC, 0>(tl, gs, tc, n, it, ROFF, sbases, lane_s, lane_c, qa); break;
+                        default: seg_done = g2_spec_segment<IN, SC, -1>(tl, gs, tc, n, it, ROFF, sbases, lane_s, lane_c, qa); break;
+                    }
+                    DSP_TR(trp, 11);
+                    DSP_TT(tt_b);
+                    if (seg_done) {
+                        if (!qb_spec)       // the block's other symbols carry per-lane flags: so must these
+                            for (int i = 0; i < n; i++) q_flag[(buf * TQ + tq + i) * 64 + lane] = 1;
+                        it += n; t += n; tq += n; n_steady += n;
                     }
                 }
-                if (!done) {
-                    const int rec_row = it + ROFF;
-                    if (gs.active && rec_row >= cap_rows) { gs.active = false; overflow = true; }
-                    dspm::GOut go = timing_iter<IN, VARIANT, (H > 0), SC>(tl, gs, tc, Lp, trp);
-                    DSP_TR(trp, 5);
-                    const int rrow = rec_row < cap_rows ? rec_row : cap_rows;
-                    const int erow = it < cap_rows ? it : cap_rows;
-                    const size_t g_off = obase + (size_t)erow * 64;
-                    if (o_rec) st_cplx(o_rec + obase + (size_t)rrow * 64, go.rec.re, go.rec.im, go.produced);
-                    if (o_terr) st_val(o_terr + g_off, go.err, go.produced);
-                    if (o_mu) st_val(o_mu + g_off, go.mu, go.produced);
-                    if (o_pos) st_val(o_pos + g_off, symbol_position<VARIANT>(gs, go, sps), go.produced);
-                    DSP_TR(trp, 6);
-                    d2v qv = {go.rec.re, go.rec.im};
-                    q_data[(buf * TQ + tq) * 64 + lane] = qv;
-                    q_flag[(buf * TQ + tq) * 64 + lane] = go.produced ? 1 : 0;
-                    n_rec += go.produced ? 1 : 0;
-                    if (steady) steady = __all(gs.active);
+                if (!seg_done) {
+                    if (qb_spec) {          // the FLL wave will read this block's flags: those of the segments behind us
+                        for (int i = 0; i < tq; i++) q_flag[(buf * TQ + i) * 64 + lane] = 1;
+                        qb_spec = false;
+                    }
+                    for (int i = 0; i < n; i++, t++, it++, tq++) {
+                        DSP_TR(trp, 0);
+                        bool done = false;
+                        if (steady && (!SPEC || !spec_cfg)) {
+                            cd rec; double e, ps;
+                            if constexpr (H > 0) done = g2_steady_lagr<IN, SC, H>(tl, gs, tc, Lp, rec, e, ps);
+                            else done = g2_steady<IN, SC>(tl, gs, tc, rec, e, ps);
+                            if (done) {
+                                DSP_TR(trp, 5);
+                                const unsigned row_s = (unsigned)it * 64u * (unsigned)sizeof(OS);
+                                const unsigned row_c = (unsigned)(it + ROFF) * 64u * (unsigned)sizeof(OC);
+                                OC rv = {(OS)rec.re, (OS)rec.im};
+                                if (o_rec) sst(rec_t, lane_c + row_c, rv);
+                                if (o_terr) sst(err_t, lane_s + row_s, (OS)e);
+                                if (o_mu) sst(mu_t, lane_s + row_s, (OS)gs.mu);
+                                if (o_pos) sst(pos_t, lane_s + row_s, (OS)ps);
+                                DSP_TR(trp, 6);
+                                d2v qv = {rec.re, rec.im};
+                                q_data[(buf * TQ + tq) * 64 + lane] = qv;
+                                q_flag[(buf * TQ + tq) * 64 + lane] = 1;
+                                n_steady++;
+                            }
+                        }
+                        if (!done) {
+                            const int rec_row = it + ROFF;
+                            if (gs.active && rec_row >= cap_rows) { gs.active = false; overflow = true; }
+                            dspm::GOut go = timing_iter<IN, VARIANT, (H > 0), SC>(tl, gs, tc, Lp, trp);
+                            DSP_TR(trp, 5);
+                            const int rrow = rec_row < cap_rows ? rec_row : cap_rows;
+                            const int erow = it < cap_rows ? it : cap_rows;
+                            const size_t g_off = obase + (size_t)erow * 64;
+                            if (o_rec) st_cplx(o_rec + obase + (size_t)rrow * 64, go.rec.re, go.rec.im, go.produced);
+                            if (o_terr) st_val(o_terr + g_off, go.err, go.produced);
+                            if (o_mu) st_val(o_mu + g_off, go.mu, go.produced);
+                            if (o_pos) st_val(o_pos + g_off, symbol_position<VARIANT>(gs, go, sps), go.produced);
+                            DSP_TR(trp, 6);
+                            d2v qv = {go.rec.re, go.rec.im};
+                            q_data[(buf * TQ + tq) * 64 + lane] = qv;
+                            q_flag[(buf * TQ + tq) * 64 + lane] = go.produced ? 1 : 0;
+                            n_rec += go.produced ? 1 : 0;
+                            if (steady) steady = __all(gs.active);
+                        }
+                        DSP_TR(trp, 7);
+                    }
                 }
-                DSP_TR(trp, 7);
-                if (++tq == TQ) {                      // hand the queue block over (uniform)
-                    more = __any(gs.active);
-                    if (lane == 0) q_more[buf] = more ? 1 : 0;
+                if (tq == TQ) {                        // hand the queue block over (uniform)
+                    // (a block of speculative segments only: every lane was active and still is)
+                    more = qb_spec ? true : __any(gs.active);
+                    if (lane == 0) q_more[buf] = (more ? 1 : 0) | (qb_spec ? 2 : 0);
+                    DSP_TT(tt_f);
                     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    DSP_TT(tt_c);
                     DSP_TR(trp, 8);
-                    tq = 0; buf ^= 1;
+                    tq = 0; buf ^= 1; qb_spec = true;
                     if (!more) break;
                 }
             }
@@ -943,28 +1281,59 @@ __global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
         int it = 0;
         prio_n = prio_n ? (prio_n * T / TQ > 0 ? prio_n * T / TQ : 1) : 0;     // same period in queue blocks
         prio_c = 1;
+        constexpr bool SPEC = (VARIANT == DSP_VARIANT_GARDNER2 && H == 0);
+        const int fmask = (o_sig ? 1 : 0) | (o_freq ? 2 : 0) | (o_ef ? 4 : 0) | (o_dec ? 8 : 0);
+        const size_t tile_el = (size_t)tile * out_rows * 64;
+        const SpecBasesF fbases = {o_sig ? (const unsigned char *)(o_sig + tile_el) : nullptr,
+                                   o_freq ? (const unsigned char *)(o_freq + tile_el) : nullptr,
+                                   o_ef ? (const unsigned char *)(o_ef + tile_el) : nullptr,
+                                   o_dec ? (const unsigned char *)(o_dec + tile_el) : nullptr};
+        const unsigned q_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)q_base + (unsigned)lane * 16u;
         for (int qb = 0;; qb++) {
             const int buf = qb & 1;
             if (prio_n && --prio_c == 0) { prio_c = prio_n; rotate_priority(slot, ++prio_ph); }
             DSP_TR(trp, 5);
+            DSP_TT(tt_d);
             asm volatile("s_barrier" ::: "memory");
+            DSP_TT(tt_c);
             DSP_TR(trp, 0);
-            const int more = q_more[buf];
-            for (int t = 0; t < TQ; t++, it++) {
-                const int row = it + ROFF;
-                d2v qv = q_data[(buf * TQ + t) * 64 + lane];
-                const bool pend = q_flag[(buf * TQ + t) * 64 + lane] != 0;
-                cd x; x.re = qv.x; x.im = qv.y;
-                DSP_TR(trp, 1);
-                if (row < cap_rows) {                                    // uniform
-                    FllLane fo = fll_iter(MK, pend, x, (double)row + i0, freq, integ, kp, ki, trp);
-                    const size_t off = obase + (size_t)row * 64;
-                    if (o_sig) st_cplx(o_sig + off, fo.sr, fo.si);
-                    if (o_freq) st_val(o_freq + off, fo.freq);
-                    if (o_ef) st_val(o_ef + off, fo.ef);
-                    if (o_dec) st_b8(o_dec + off, fo.quad);
+            const unsigned qa0 = q_lds + (unsigned)(buf * TQ) * 1024u;
+            const int qfl = q_more[buf];
+            const d2v x0 = lds_ld<d2v>(qa0);                 // in flight while the flags decide the path
+            const int more = qfl & 1;
+            bool blk_done = false;
+            if (SPEC && (qfl & 2) && it + TQ + ROFF < cap_rows &&
+                (unsigned long long)(it + TQ + ROFF + 1) * 64ull * sizeof(OC) <= 0xffffffffull) {
+                const unsigned qa = qa0;
+                switch (fmask) {
+                    case 15: blk_done = fll_spec_block<OS, OC, 15>(MK, TQ, qa, x0, it + ROFF, i0, freq, integ, kp, ki, fbases, (unsigned)lane); break;
+                    case 10: blk_done = fll_spec_block<OS, OC, 10>(MK, TQ, qa, x0, it + ROFF, i0, freq, integ, kp, ki, fbases, (unsigned)lane); break;
+                    case 8: blk_done = fll_spec_block<OS, OC, 8>(MK, TQ, qa, x0, it + ROFF, i0, freq, integ, kp, ki, fbases, (unsigned)lane); break;
+                    case 0: blk_done = fll_spec_block<OS, OC, 0>(MK, TQ, qa, x0, it + ROFF, i0, freq, integ, kp, ki, fbases, (unsigned)lane); break;
+                    default: blk_done = fll_spec_block<OS, OC, -1>(MK, TQ, qa, x0, it + ROFF, i0, freq, integ, kp, ki, fbases, (unsigned)lane); break;
                 }
-                DSP_TR(trp, 5);
+                DSP_TR(trp, 12);
+                DSP_TT(tt_b);
+                if (blk_done) it += TQ;
+            }
+            if (!blk_done) {
+                for (int t = 0; t < TQ; t++, it++) {
+                    const int row = it + ROFF;
+                    d2v qv = q_data[(buf * TQ + t) * 64 + lane];
+                    // (a block the timing wave marked speculative carries no flags: every lane produced)
+                    const bool pend = (qfl & 2) ? true : q_flag[(buf * TQ + t) * 64 + lane] != 0;
+                    cd x; x.re = qv.x; x.im = qv.y;
+                    DSP_TR(trp, 1);
+                    if (row < cap_rows) {                                    // uniform
+                        FllLane fo = fll_iter(MK, pend, x, (double)row + i0, freq, integ, kp, ki, trp);
+                        const size_t off = obase + (size_t)row * 64;
+                        if (o_sig) st_cplx(o_sig + off, fo.sr, fo.si);
+                        if (o_freq) st_val(o_freq + off, fo.freq);
+                        if (o_ef) st_val(o_ef + off, fo.ef);
+                        if (o_dec) st_b8(o_dec + off, fo.quad);
+                    }
+                    DSP_TR(trp, 5);
+                }
             }
             if (!more) break;
         }
@@ -979,6 +1348,10 @@ __global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
             unsigned long long *t = P.trace + ((size_t)tile * 2 + role) * 20;
             t[0] = tr_t0; t[1] = tr_t1; t[2] = hw; t[3] = xcc;
             for (int i = 0; i < 16; i++) t[4 + i] = tr_acc.acc[i];
+#if !defined(DSP_TRACE_STAMPS)
+            t[4] = tt_a; t[5] = tt_b; t[6] = tt_c; t[7] = tt_d;     // advance / segments (blocks) / barrier / the rest
+            t[8] = tt_e; t[9] = tt_f;                               // timing wave: block head -> segment, segment -> hand-over
+#endif
         }
     }
 #endif
@@ -1038,7 +1411,7 @@ SyncPlan sync_plan(int elem_bytes, int sps, int half_len, int variant, int n_sto
     C += C & 1;
     int slack = (variant == DSP_VARIANT_NONE) ? 0 : step;
     int T = ((R - C - h - slack) / step - 1) / 2;
-    if (T > 8) T = 8;
+    if (T > 14) T = 14;                           // (8 until round 3: every block costs a DMA wait, an issue loop and a vote)
     if (n_store > 0) while (T > 1 && T * n_store > 63) T--;
     if ((step * T) % rpp) T -= 1;                 // whole DMA pieces per block
     pl.ring_rows = R;

@@ -34,6 +34,37 @@ double hm_fll(const double *x, int64_t M, double kp, double ki, int64_t i0, doub
     return f;
 }
 
+// the same loop through the restated step (fll_step_fast) in blocks of `blk` symbols with the kernel's
+// rule: a block in which a component of a derotated sample was exactly zero (or the quadrant index
+// left the int32 range) is run again from its start state through fll_step.  Returns the number of
+// blocks that were run again.
+int64_t hm_fll_fast(const double *x, int64_t M, double kp, double ki, int64_t i0, int64_t blk, double *out,
+                    double *freq, double *ef, uint8_t *quad, double *final_freq)
+{
+    double f = 0.0, integ = 0.0;
+    int64_t redone = 0;
+    for (int64_t b0 = 0; b0 < M; b0 += blk) {
+        const int64_t n = M - b0 < blk ? M - b0 : blk;
+        const double f0 = f, g0 = integ;
+        FllEvidence ev;
+        fll_evidence_init(ev);
+        for (int64_t i = b0; i < b0 + n; i++) {
+            const double idx = (double)(i + i0);
+            FllOut o = fll_step_fast(KK, x[2 * i], x[2 * i + 1], idx, 4.0 * idx, f, integ, kp, ki, ev);
+            out[2 * i] = o.sr; out[2 * i + 1] = o.si; freq[i] = o.freq; ef[i] = o.ef; quad[i] = (uint8_t)o.quad;
+        }
+        if (fll_evidence_bad(ev)) {
+            f = f0; integ = g0; redone++;
+            for (int64_t i = b0; i < b0 + n; i++) {
+                FllOut o = fll_step(KK, x[2 * i], x[2 * i + 1], (double)(i + i0), f, integ, kp, ki);
+                out[2 * i] = o.sr; out[2 * i + 1] = o.si; freq[i] = o.freq; ef[i] = o.ef; quad[i] = (uint8_t)o.quad;
+            }
+        }
+    }
+    *final_freq = f;
+    return redone;
+}
+
 struct ArrFetch {
     const double *x; double scale;
     cd operator()(int row) const { cd v; v.re = x[2 * row] * scale; v.im = x[2 * row + 1] * scale; return v; }

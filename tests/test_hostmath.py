@@ -117,6 +117,56 @@ def test_fll_vs_reference(hm):
     assert np.max(np.abs(out - ge["fll_axis_out"])) < 1e-13
 
 
+def hm_fll_fast(L, x, Bn, y, i0=0, blk=8):
+    x = np.ascontiguousarray(x, np.complex128)
+    M = x.size
+    kp = 4 * Bn / 1000 / (y + 1 / (4 * y))
+    ki = 4 * (Bn / 1000 / (y + 1 / (4 * y))) ** 2
+    out = np.empty(M, np.complex128); fr = np.empty(M); ef = np.empty(M); q = np.empty(M, np.uint8)
+    cf = C.c_double(0.0)
+    L.hm_fll_fast.restype = C.c_int64
+    redone = L.hm_fll_fast(_p(x), C.c_int64(M), C.c_double(kp), C.c_double(ki), C.c_int64(i0), C.c_int64(blk),
+                           _p(out), _p(fr), _p(ef), _p(q), C.byref(cf))
+    return out, cf.value, fr, ef, q, redone
+
+
+def test_fll_fast_step_vs_reference(hm):
+    """fll_step_fast (the restated iteration the two-wave kernel runs on blocks whose lanes are all live)
+    against the reference's vectors with the bars of fll_step, and against fll_step itself."""
+    g = golden("g_config1")
+    out, cf, fr, ef, q, redone = hm_fll_fast(hm, g["rec"], 0.03, 1)
+    H = 3300
+    assert redone == 0
+    assert np.max(np.abs(fr[:H] - g["fll_freq"][:H])) < 1e-15
+    assert np.array_equal(q[:H], g["dec"][:H])
+    g2 = golden("g_config2")
+    out, cf, fr, ef, q, redone = hm_fll_fast(hm, g2["y"][0::4], 1e-6, 1)
+    assert np.max(np.abs(fr - g2["fllA_freq"])) < 1e-20
+    assert np.max(np.abs(out - g2["fllA_out"])) < 1e-13
+    gs = golden("g_synth_bursts")
+    for b in range(6):
+        n = int(gs["n_recB"][b])
+        out, cf, fr, ef, q, redone = hm_fll_fast(hm, gs["recB"][b, :n], 0.03, 1, blk=3 + b)
+        assert np.max(np.abs(fr - gs["fllB_freq"][b, :n])) < 1e-16
+        assert np.array_equal(q, gs["decB"][b, :n])
+        o0, c0, f0, e0, q0 = hm_fll(hm, gs["recB"][b, :n], 0.03, 1)
+        assert np.max(np.abs(out - o0)) < 1e-15 * np.max(np.abs(o0)) and np.max(np.abs(ef - e0)) < 1e-19
+    # samples on the axes (a component exactly zero: np.sign(0) = 0): such blocks are run again
+    # through fll_step, so the result is fll_step's
+    ge = golden("g_edges")
+    out, cf, fr, ef, q, redone = hm_fll_fast(hm, ge["fll_axis_x"], 50.0, 1, blk=4)
+    assert redone > 0
+    assert np.max(np.abs(fr - ge["fll_axis_freq"])) < 1e-15
+    assert np.max(np.abs(out - ge["fll_axis_out"])) < 1e-13
+    # large absolute indices (inside the loop's stability horizon 1/(pi*kp) for this Bn)
+    rng = np.random.default_rng(3)
+    x = np.exp(2j * np.pi * (1e-7 * np.arange(4000) + rng.uniform(0, 1))) * (1 + 0.1 * rng.standard_normal(4000))
+    a = hm_fll_fast(hm, x, 1e-5, 1, i0=2_000_000, blk=6)
+    b = hm_fll(hm, x, 1e-5, 1, i0=2_000_000)
+    assert a[5] == 0 and np.max(np.abs(a[2] - b[2])) < 1e-18 and np.array_equal(a[4], b[4])
+    assert np.max(np.abs(a[0] - b[0])) < 1e-15 * 1.5
+
+
 def test_lagrange_vs_reference(hm):
     g = golden("g_lagrange")
     x = np.ascontiguousarray(g["clean"], np.complex128)

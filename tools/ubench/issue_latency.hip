@@ -88,6 +88,22 @@ KERNEL(k_waitcnt_only, 1, "s_waitcnt lgkmcnt(0)")
 KERNEL(k_snop, 1, "s_nop 0")
 KERNEL(k_cvt_i32_dep, 2, "v_cvt_i32_f64 %6, %0\n v_and_b32 %6, %6, %7")
 
+// round 3: what makes v_cndmask slow (19 ticks with vcc above)
+KERNEL(k_cnd_vcc_e64, 1, "v_cndmask_b32_e64 %4, %4, %5, vcc")
+KERNEL(k_cmp_4cnd_vcc, 5, "v_cmp_gt_f64 vcc, %0, %1\n v_cndmask_b32 %4, %4, %10, vcc\n v_cndmask_b32 %5, %5, %11, vcc\n v_cndmask_b32 %6, %6, %7, vcc\n v_cndmask_b32 %7, %7, %6, vcc")
+KERNEL(k_cmp_4cnd_sgpr, 5, "v_cmp_gt_f64 s[20:21], %0, %1\n v_cndmask_b32_e64 %4, %4, %10, s[20:21]\n v_cndmask_b32_e64 %5, %5, %11, s[20:21]\n v_cndmask_b32_e64 %6, %6, %7, s[20:21]\n v_cndmask_b32_e64 %7, %7, %6, s[20:21]")
+KERNEL(k_cmp_1cnd_3fma, 5, "v_cmp_gt_f64 vcc, %0, %1\n v_cndmask_b32 %4, %4, %10, vcc\n v_fma_f64 %1, %1, %8, %9\n v_fma_f64 %2, %2, %8, %9\n v_fma_f64 %3, %3, %8, %9")
+KERNEL(k_2cnd_vcc_2fma, 4, "v_cndmask_b32 %4, %4, %10, vcc\n v_fma_f64 %1, %1, %8, %9\n v_cndmask_b32 %5, %5, %11, vcc\n v_fma_f64 %2, %2, %8, %9")
+KERNEL(k_bfi_2, 2, "v_bfi_b32 %6, %7, %6, %4\n v_bfi_b32 %5, %7, %5, %4")
+KERNEL(k_minmax64, 2, "v_min_f64 %0, %0, %8\n v_max_f64 %1, %1, %9")
+KERNEL(k_maxu_ashr, 2, "v_max_u32 %6, %6, %7\n v_ashrrev_i32 %7, 31, %7")
+KERNEL(k_addco, 2, "v_add_co_u32 %6, vcc, %6, %7\n v_addc_co_u32 %7, vcc, %7, %6, vcc")
+KERNEL(k_and_or, 2, "v_and_or_b32 %6, %6, %7, %4\n v_lshl_add_u32 %7, %7, 9, %5")
+KERNEL(k_cvt_f32_f64_2, 2, "v_cvt_f32_f64 %4, %0\n v_cvt_f32_f64 %5, %1")
+KERNEL(k_ds_write64, 1, "ds_write_b64 %6, %0")
+KERNEL(k_ds_read8_nowait, 8, "ds_read_b64 %0, %6\n ds_read_b64 %1, %6 offset:512\n ds_read_b64 %2, %6 offset:1024\n ds_read_b64 %3, %6 offset:1536\n ds_read_b64 %0, %6 offset:2048\n ds_read_b64 %1, %6 offset:2560\n ds_read_b64 %2, %6 offset:3072\n ds_read_b64 %3, %6 offset:3584")
+KERNEL(k_vote_sgpr, 3, "v_cmp_gt_f64 s[20:21], %0, %1\n s_cmp_eq_u64 s[20:21], 0\n s_cbranch_scc1 1f\n1:")
+
 typedef void (*kern_t)(double *, unsigned long long *, int, double, double);
 struct Case { const char *name; kern_t k; int n; };
 
@@ -104,7 +120,10 @@ int main()
         C(k_pk_fma32, 1), C(k_ds_read, 1), C(k_cmp_sand_cnd, 3), C(k_cmp_cnd_e64, 2), C(k_cmp_cnd_dep, 2),
         C(k_cmp_vote_nt, 3), C(k_cmp_vccz_nt, 2), C(k_branch_taken, 2), C(k_readfirstlane, 2), C(k_salu_dep, 1),
         C(k_salu_2, 2), C(k_fma64_salu2, 2), C(k_fma64_3salu, 4), C(k_saveexec, 3), C(k_ds_write_read, 2),
-        C(k_ds_read6, 6), C(k_waitcnt_only, 1), C(k_snop, 1), C(k_cvt_i32_dep, 2)};
+        C(k_ds_read6, 6), C(k_waitcnt_only, 1), C(k_snop, 1), C(k_cvt_i32_dep, 2),
+        C(k_cnd_vcc_e64, 1), C(k_cmp_4cnd_vcc, 5), C(k_cmp_4cnd_sgpr, 5), C(k_cmp_1cnd_3fma, 5), C(k_2cnd_vcc_2fma, 4),
+        C(k_bfi_2, 2), C(k_minmax64, 2), C(k_maxu_ashr, 2), C(k_addco, 2), C(k_and_or, 2), C(k_cvt_f32_f64_2, 2),
+        C(k_ds_write64, 1), C(k_ds_read8_nowait, 8), C(k_vote_sgpr, 3)};
     const int iters = 1000;
     const int nbs[3] = {1024, 2048, 4096};        // 1, 2, 4 waves per SIMD on 256 CUs
     double *out; unsigned long long *cyc;

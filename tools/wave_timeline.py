@@ -96,6 +96,19 @@ if os.environ.get("TRACE_STAMPS"):
     print("F wave, ticks per symbol (total %.0f):" % seg[1].sum())
     for i, n in enumerate(names_f):
         print(f"   {n:26s} {seg[1, i]:8.1f}  {100 * seg[1, i] / seg[1].sum():5.1f}%")
+if not os.environ.get("TRACE_STAMPS"):
+    # trace build without stamps: four coarse register timers per wave (sync_kernels.hip DSP_TT)
+    seg = tr[..., 4:10].astype(np.float64).mean(axis=0) / 2048.0
+    tot = life.astype(np.float64).mean(axis=0) / 2048.0
+    print("ticks per symbol        DMA wait+issue   segments/blocks   barrier   rest   head->segment   segment->hand-over  (lifetime)")
+    for w, name in enumerate(("timing wave", "FLL wave")):
+        print(f"  {name:14s} {seg[w, 0]:14.0f} {seg[w, 1]:17.0f} {seg[w, 2]:9.0f} {seg[w, 3]:6.0f} {seg[w, 4]:14.0f} {seg[w, 5]:18.0f}     {tot[w]:.0f}")
+if os.environ.get("TRACE_STAMPS"):
+    # round 3 (speculative segments): coarse stamps only -- per symbol, all 16 slots of both waves
+    print("G raw ticks/symbol:", " ".join(f"{i}:{v:.0f}" for i, v in enumerate(seg[0])))
+    print("   9 = DMA wait + issue, 10 = block bookkeeping in front of a segment, 11 = inside speculative segments, 8 = hand-over + barrier")
+    print("F raw ticks/symbol:", " ".join(f"{i}:{v:.0f}" for i, v in enumerate(seg[1])))
+    print("   0 = barrier wait, 12 = inside speculative blocks (flag read + dispatch + loop + vote), 5 = loop tail")
 ctx.free(d_tr)
 pipe.close()
 ctx.close()
