@@ -630,11 +630,11 @@ static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, c
     // many tiles a CU holds (160 KiB per CU), so size it for an even spread over 256 CUs.
     const int elem = a->dtype == DSP_C128 ? 16 : 8;
     const int ntiles = (P.B + 63) / 64;
-    // two waves per tile: both loops run, and the interpolator is the reference's linear one or the
-    // Lagrange one the two-wave kernel is built for (gardner2 variant, half_len 1, 2, 4)
-    const bool can_split = fll && a->variant != 2 &&
-                           (P.half_len == 0 || (a->variant == DSP_GARDNER2 &&
-                                                (P.half_len == 1 || P.half_len == 2 || P.half_len == 4)));
+    // two waves per tile: both loops run, and the interpolator is the reference's linear one or a
+    // Lagrange order the two-wave kernel is built for (half_len 1, 2, 3, 4, 6, 8; sync_kernels.hip parts 1-4)
+    const bool lagr_built = P.half_len == 1 || P.half_len == 2 || P.half_len == 3 || P.half_len == 4 ||
+                            P.half_len == 6 || P.half_len == 8;
+    const bool can_split = fll && a->variant != 2 && (P.half_len == 0 || lagr_built);
     const int n_store_t = count_nonnull({P.rec, P.terr, P.mu, P.pos});
     const int n_store_f = count_nonnull({P.sig, P.freq, P.ef, P.dec});
     int per_cu = (ntiles + c->n_cu - 1) / c->n_cu;
@@ -718,7 +718,7 @@ static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, c
         // two 2-wave workgroups per CU land on three SIMDs (sync_kernels.hip); the idle middle wave
         // spreads them over four.  Measured: 512 tiles 1.57 -> 1.30 ms; no gain at one workgroup per
         // CU, 3 % slower at three or four, and at eight the spare waves cost occupancy
-        P.spare_wave = c->spare_wave >= 0 ? c->spare_wave : (per_cu == 2 && P.half_len == 0 ? 2 : 0);
+        P.spare_wave = c->spare_wave >= 0 ? c->spare_wave : (per_cu == 2 ? 2 : 0);
         P.cu_tickets = c->cu_tickets;
         P.place = c->place;
         P.spec = c->spec;

@@ -25,10 +25,10 @@
 #include "dsp_internal.h"
 #include "sync_lane.h"
 
-// This file is compiled twice (Makefile): part 0 holds every kernel with the reference's linear
-// interpolator, the one-wave kernels and the launch logic; part 1 (-DDSP_SYNC_PART=1) only the
-// two-wave kernel with the Lagrange interpolator inside the timing loop (half_len 1, 2, 4), so that
-// the two sets of instantiations build side by side.
+// This file is compiled five times (Makefile): part 0 holds every kernel with the reference's linear
+// interpolator, the one-wave kernels and the launch logic; parts 1-4 (-DDSP_SYNC_PART=n) only the
+// two-wave kernel with the Lagrange interpolator inside the timing loop (gardner2 / gardner_ted, half_len
+// 1, 2, 4 / 3, 6, 8), so that the sets of instantiations build side by side.
 #ifndef DSP_SYNC_PART
 #define DSP_SYNC_PART 0
 #endif
@@ -1357,25 +1357,44 @@ __global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
 #endif
 }
 
-#if DSP_SYNC_PART == 1
-// the two-wave kernel with the Lagrange interpolator: half_len 1, 2 or 4, gardner2 variant, launched
-// with two waves per tile or with four (two of them chosen by the CU ticket, see above)
+#if DSP_SYNC_PART >= 1
+// The two-wave kernel with the Lagrange interpolator inside the timing loop, one translation unit per
+// (variant, set of orders) so that they build side by side:
+//   part 1  gardner2, half_len 1, 2, 4      part 2  gardner2, half_len 3, 6, 8
+//   part 3  gardner_ted, half_len 1, 2, 4   part 4  gardner_ted, half_len 3, 6, 8
+// gardner2: straight-line steady iteration (g2_steady_lagr), two waves per tile or four (two of them
+// chosen by the CU ticket, see above).  gardner_ted: the per-lane iteration (ted_iter + lagrange_at) on
+// the timing wave, the FLL on its own wave.
+#if DSP_SYNC_PART == 1 || DSP_SYNC_PART == 3
+#define DSP_LAGR_HA 1
+#define DSP_LAGR_HB 2
+#define DSP_LAGR_HC 4
+#else
+#define DSP_LAGR_HA 3
+#define DSP_LAGR_HB 6
+#define DSP_LAGR_HC 8
+#endif
 template <typename IN>
 static hipError_t launch_split_lagr_t(const SyncParams &P, size_t lds, hipStream_t s)
 {
+    constexpr int VAR = DSP_SYNC_PART <= 2 ? DSP_VARIANT_GARDNER2 : DSP_VARIANT_TED;
     const int ntiles = (P.B + 63) / 64;
-    const bool four = P.spare_wave == 2 && P.cu_tickets;
+    const bool four = VAR == DSP_VARIANT_GARDNER2 && P.spare_wave == 2 && P.cu_tickets;
     void (*k)(SyncParams) = nullptr;
-#define DSP_LAGR_PICK(HH)                                                                      \
-    k = four ? sync_split_kernel<IN, DSP_VARIANT_GARDNER2, true, 4, HH>                         \
-             : sync_split_kernel<IN, DSP_VARIANT_GARDNER2, true, 2, HH>
+    auto pick = [&](auto hc) {
+        constexpr int HH = decltype(hc)::value;
+        if constexpr (VAR == DSP_VARIANT_GARDNER2) {
+            k = four ? sync_split_kernel<IN, VAR, true, 4, HH> : sync_split_kernel<IN, VAR, true, 2, HH>;
+        } else {
+            k = sync_split_kernel<IN, VAR, true, 2, HH>;
+        }
+    };
     switch (P.half_len) {
-        case 1: DSP_LAGR_PICK(1); break;
-        case 2: DSP_LAGR_PICK(2); break;
-        case 4: DSP_LAGR_PICK(4); break;
+        case DSP_LAGR_HA: pick(std::integral_constant<int, DSP_LAGR_HA>{}); break;
+        case DSP_LAGR_HB: pick(std::integral_constant<int, DSP_LAGR_HB>{}); break;
+        case DSP_LAGR_HC: pick(std::integral_constant<int, DSP_LAGR_HC>{}); break;
         default: return hipErrorInvalidValue;
     }
-#undef DSP_LAGR_PICK
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1387,13 +1406,18 @@ static hipError_t launch_split_lagr_t(const SyncParams &P, size_t lds, hipStream
 
 }  // namespace
 
-#if DSP_SYNC_PART == 1
-hipError_t launch_sync_split_lagr(const SyncParams &P, bool c128, size_t lds, hipStream_t s)
+#define DSP_CAT2(a, b) a##b
+#define DSP_CAT(a, b) DSP_CAT2(a, b)
+#if DSP_SYNC_PART >= 1
+hipError_t DSP_CAT(launch_sync_split_lagr_part, DSP_SYNC_PART)(const SyncParams &P, bool c128, size_t lds, hipStream_t s)
 {
     return c128 ? launch_split_lagr_t<d2v>(P, lds, s) : launch_split_lagr_t<f2v>(P, lds, s);
 }
 #else
-hipError_t launch_sync_split_lagr(const SyncParams &P, bool c128, size_t lds, hipStream_t s);
+hipError_t launch_sync_split_lagr_part1(const SyncParams &P, bool c128, size_t lds, hipStream_t s);
+hipError_t launch_sync_split_lagr_part2(const SyncParams &P, bool c128, size_t lds, hipStream_t s);
+hipError_t launch_sync_split_lagr_part3(const SyncParams &P, bool c128, size_t lds, hipStream_t s);
+hipError_t launch_sync_split_lagr_part4(const SyncParams &P, bool c128, size_t lds, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // Ring schedule.  Iteration `it` of the timing loop touches rows
@@ -1440,8 +1464,14 @@ static hipError_t launch_v(const SyncParams &P, size_t lds, hipStream_t s)
 template <typename IN>
 static hipError_t launch_in(const SyncParams &P, int variant, bool fll, size_t lds, hipStream_t s)
 {
-    if (P.TQ > 0 && P.half_len > 0)   // ... with the Lagrange interpolator: the other translation unit
-        return launch_sync_split_lagr(P, sizeof(IN) == 16, lds, s);
+    if (P.TQ > 0 && P.half_len > 0) { // ... with the Lagrange interpolator: the other translation units
+        const bool set2 = P.half_len == 3 || P.half_len == 6 || P.half_len == 8;
+        if (variant == DSP_VARIANT_GARDNER2)
+            return set2 ? launch_sync_split_lagr_part2(P, sizeof(IN) == 16, lds, s)
+                        : launch_sync_split_lagr_part1(P, sizeof(IN) == 16, lds, s);
+        return set2 ? launch_sync_split_lagr_part4(P, sizeof(IN) == 16, lds, s)
+                    : launch_sync_split_lagr_part3(P, sizeof(IN) == 16, lds, s);
+    }
     if (P.TQ > 0) {        // two waves per tile (timing wave + FLL wave)
         int ntiles = (P.B + 63) / 64;
         const int nwv = P.spare_wave == 2 && P.cu_tickets ? 4 : P.spare_wave ? 3 : 2;

@@ -94,8 +94,11 @@ def test_gardner_with_lagrange_interpolator(oracle, ctx):
     assert np.mean(a["dec"][0, 50:na] == b["dec"][0, 50:na]) > 0.99
 
 
-def test_lagrange_two_wave_kernel_full_tiles_ragged(oracle, ctx):
-    """interp_half_len 1, 2, 4 through the fused chain (both loops -> the two-wave kernel, whose timing
+@pytest.mark.parametrize("halves,picks", [((1, 2, 4), list(range(0, 70, 9)) + [1, 2, 3, 63, 64, 69]),
+                                          ((3, 6, 8), [0, 1, 2, 3, 36, 63, 64, 69])])
+def test_lagrange_two_wave_kernel_full_tiles_ragged(oracle, ctx, halves, picks):
+    """interp_half_len 1, 2, 4 (round 2) and 3, 6, 8 (round 3: 6 is the order of the reference's own worked
+    Lagrange scenario, hw1/test_lagrange_resampling.py:157) through the fused chain (both loops -> the two-wave kernel, whose timing
     wave interpolates out of the LDS ring with product-form Lagrange basis values): full tiles of
     bursts with ragged lengths, every burst against the restated loop to 1e-12 -- the per-lane code
     (barycentric form) serves burst starts, ends and idle lanes, the straight-line code the rest --
@@ -110,7 +113,7 @@ def test_lagrange_two_wave_kernel_full_tiles_ragged(oracle, ctx):
     rng = np.random.default_rng(41)
     lens = rng.integers(1200, N + 1, 70).astype(np.int32)
     lens[:4] = [N, N - 1, 1200, 1777]
-    for half in (1, 2, 4):
+    for half in halves:
         r = dsp_amd.sync_chain_batch(Y, 4, 0.007, 0.0, 0.03, 1, interp_half_len=half, lens=lens,
                                      outputs=("rec", "err", "mu", "dec", "freq"), ctx=ctx)
         ctx.set_option("split", 0)
@@ -120,7 +123,7 @@ def test_lagrange_two_wave_kernel_full_tiles_ragged(oracle, ctx):
         finally:
             ctx.set_option("split", -1)
         assert np.array_equal(r["n_out"], r1["n_out"])
-        for b in list(range(0, 70, 9)) + [1, 2, 3, 63, 64, 69]:
+        for b in picks:
             L = int(lens[b])
             rec, err, mu = gardner2_lagrange_restated(oracle, Y[b, :L], 4, 0.007, half)
             n = int(r["n_out"][b])
@@ -133,3 +136,57 @@ def test_lagrange_two_wave_kernel_full_tiles_ragged(oracle, ctx):
             assert np.array_equal(r["dec"][b, :n], oracle.quadrants(out[0])), (half, b)
             assert np.max(np.abs(r["freq"][b, :n] - out[2])) < 1e-12
             assert not r["rec"][b, n:].any()
+
+
+def gardner_ted_lagrange_restated(oracle, x, sps, delta_mu, h):
+    """hw1/gardner.py:45-72 with interpolate_sample replaced by the (2h+1)-point Lagrange interpolator
+    (lagrange_resample's own clipping at the ends)."""
+    x = np.asarray(x, np.complex128)
+    n = len(x)
+
+    def interp(idx):
+        return oracle.lagrange_resample(x, np.array([idx]), h)[0]
+
+    ys, errs, mus = [], [], []
+    mu = 0.0
+    for k in range((n - 2 * sps) // sps):
+        i_k, i_n, i_m = k * sps + mu, (k + 1) * sps + mu, k * sps + mu + sps / 2.0
+        if i_n + 1 >= n or i_m + 1 >= n:
+            break
+        xk, xn, xm = interp(i_k), interp(i_n), interp(i_m)
+        e = float(np.real(xm * np.conj(xn - xk)))
+        ys.append(xk); errs.append(e); mus.append(mu)
+        mu = float(np.clip(mu + delta_mu * e, -sps, sps))
+    return np.array(ys), np.array(errs), np.array(mus)
+
+
+def test_gardner_ted_with_lagrange_on_the_two_wave_kernel(oracle, ctx):
+    """The gardner_ted variant with the Lagrange interpolator and the FLL behind it: two waves per tile since
+    round 3 (timing wave: per-lane ted_iter + lagrange_at; FLL wave in parallel), every order the
+    two-wave kernel is built for, against the restated loop and the one-wave kernel."""
+    import dsp_amd
+    g = golden("g_synth_bursts")
+    h = oracle.rrc_filter(4, 10, 0.35)
+    Y = np.stack([oracle.filter_samples(g["x"][b % 32], h)[:1500] for b in range(66)])
+    Y = Y * (1.0 + 0.02 * np.arange(66))[:, None]
+    lens = np.full(66, 1500, np.int32)
+    lens[:3] = [1500, 1203, 900]
+    for half in (1, 2, 3, 4, 6, 8):
+        r = dsp_amd.sync_chain_batch(Y, 4, 0.002, 0.0, 0.03, 1, variant=1, interp_half_len=half,
+                                     lens=lens, outputs=("rec", "err", "mu", "dec", "freq"), ctx=ctx)
+        ctx.set_option("split", 0)
+        try:
+            r1 = dsp_amd.sync_chain_batch(Y, 4, 0.002, 0.0, 0.03, 1, variant=1, interp_half_len=half,
+                                          lens=lens, outputs=("rec", "err", "mu", "dec", "freq"), ctx=ctx)
+        finally:
+            ctx.set_option("split", -1)
+        for k in ("n_out", "rec", "err", "mu", "dec"):
+            assert np.array_equal(r[k], r1[k]), (half, k)          # same per-lane code on either kernel
+        for b in (0, 1, 2, 65):
+            y, err, mu = gardner_ted_lagrange_restated(oracle, Y[b, :int(lens[b])], 4, 0.002, half)
+            n = int(r["n_out"][b])
+            assert n == len(y), (half, b)
+            assert np.max(np.abs(r["mu"][b, :n] - mu)) < 1e-12 and np.max(np.abs(r["err"][b, :n] - err)) < 1e-12
+            assert np.max(np.abs(r["rec"][b, :n] - y)) < 1e-12
+            out = oracle.fll_func(y, 0.03, 1)
+            assert np.array_equal(r["dec"][b, :n], oracle.quadrants(out[0])), (half, b)

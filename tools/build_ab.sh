@@ -15,8 +15,10 @@ for f in dsp_api sync_kernels tile_kernels fir_kernels synth_kernels segment_ker
   ( hipcc $FLAGS -c $SRC/$f.hip -o $OUT/$f.o && hipcc $FLAGS $SFLAGS $SRC/$f.hip -o $OUT/$f.lint.s ) & pids+=($!)
 done
 FLAGS_L="${FLAGS% $EXTRA} $EXTRA_LAGR"
-( hipcc $FLAGS_L -DDSP_SYNC_PART=1 -c $SRC/sync_kernels.hip -o $OUT/sync_kernels_lagr.o &&
-  hipcc $FLAGS_L -DDSP_SYNC_PART=1 $SFLAGS $SRC/sync_kernels.hip -o $OUT/sync_kernels_lagr.lint.s ) & pids+=($!)
+for part in 1 2 3 4; do
+( hipcc $FLAGS_L -DDSP_SYNC_PART=$part -c $SRC/sync_kernels.hip -o $OUT/sync_kernels_p$part.o &&
+  hipcc $FLAGS_L -DDSP_SYNC_PART=$part $SFLAGS $SRC/sync_kernels.hip -o $OUT/sync_kernels_p$part.lint.s ) & pids+=($!)
+done
 for p in "${pids[@]}"; do wait $p; done
 python3 $ROOT/tools/isa_lint.py $OUT/*.lint.s
 hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/ab_libs/libdsp_$NAME.so $OUT/*.o

@@ -12,13 +12,16 @@ from dsp_amd.pipeline import BurstPipeline                   # noqa: E402
 B = int(sys.argv[1])
 ctx = dsp_amd.Context(0)
 drop = []
+half = 0
 for a in sys.argv[2:]:
     k, v = a.split("=")
-    if k == "drop":                      # drop=rec,err,mu,sig,freq,ef,dec : outputs not asked for
+    if k == "half":                      # half=H : (2H+1)-point Lagrange interpolator in the timing loop
+        half = int(v)
+    elif k == "drop":                      # drop=rec,err,mu,sig,freq,ef,dec : outputs not asked for
         drop = v.split(",")
     else:
         ctx.set_option(k, int(v))
-pipe = BurstPipeline(ctx, B, 2048, 4)
+pipe = BurstPipeline(ctx, B, 2048, 4, interp_half_len=half)
 pipe.generate()
 pipe.matched_filter(free_raw=True)
 for k in drop:
