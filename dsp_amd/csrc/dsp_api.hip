@@ -26,6 +26,7 @@ struct dsp_ctx {
     int batch_split;    // 1 (default): a batch of more tiles than the CUs keep resident goes out as several launches
     int queue_block;    // split kernel: symbols per hand-off block, 0 = automatic
     int lead_copy;      // segment-parallel mode, warm-up rows: 0 = the filter's second store, 1 = seg_lead_copy_k, 2 = filtered per window
+    int guard;          // split kernel: guard rows behind the LDS ring where they fit (1, default) or never (0)
     int spec;           // split kernel, linear interpolator: speculative branch-free segments (1, default) or the per-symbol votes (0)
     int spare_wave;     // split kernel, idle waves for SIMD balance: -1 auto, 0 never, 1 three waves, 2 four waves + CU tickets
     unsigned *cu_tickets;   // [4096] per-CU workgroup counters for the four-wave launch
@@ -244,6 +245,7 @@ int dsp_create(int device_id, dsp_ctx **out)
     c->prio_period = -1;
     c->spare_wave = -1;
     c->spec = 1;
+    c->guard = 1;
     c->lead_copy = 0;
     c->fir_stream = 2;
     c->corr_window = 1;
@@ -372,6 +374,8 @@ int dsp_set_option(dsp_ctx *c, const char *name, int64_t value)
     } else if (!strcmp(name, "lead_copy")) {
         if (value < 0 || value > 2) return fail(DSP_E_ARG, "lead_copy must be 0, 1 or 2");
         c->lead_copy = (int)value;
+    } else if (!strcmp(name, "guard")) {
+        c->guard = value != 0;
     } else if (!strcmp(name, "spec")) {
         c->spec = value != 0;
     } else if (!strcmp(name, "spare_wave")) {
@@ -683,6 +687,15 @@ static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, c
     if (split) {
         // queue block: as many symbols as the double buffer can hold inside the budget
         const size_t room = (lds + queue_min > budget ? budget_all : budget) - 32;
+        // Guard rows behind the ring (sync_kernels.hip Tile::mirror) where the LDS share has room for them and
+        // a queue of at least four symbols: 8 rows (4 KiB complex64) buy one LDS address per symbol instead of
+        // eight.  At four tiles per CU (40 KiB each: 32 KiB ring + three-symbol queue) they would leave the
+        // queue one symbol, so that shape keeps the masked addresses.
+        P.guard_rows = 0;
+        if (c->guard != 0 && c->spec && P.use_ring && a->variant == DSP_GARDNER2 && P.half_len == 0 && sps + 2 <= 8) {
+            const size_t gbytes = (size_t)8 * 64 * elem;
+            if (lds + gbytes + (size_t)2 * 4 * 64 * 17 + 16 <= room) { P.guard_rows = 8; lds += gbytes; }
+        }
         int TQ = c->queue_block;
         if (TQ == 0) {
             TQ = 1;

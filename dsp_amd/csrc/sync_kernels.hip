@@ -254,6 +254,7 @@ struct Tile {
     unsigned lds_base;            // LDS byte address of the ring
     int lane, RM, R, in_rows;
     int col;                      // the column this lane reads (its own; a passenger lane reads another burst's)
+    int guard;                    // rows behind the ring that mirror its first rows (0 or 8)
     int win_lo, win_hi;           // rows [win_lo, win_hi) are valid in the ring
     int F;                        // DMA front: rows [0, F) have been issued
     double scale;
@@ -305,9 +306,27 @@ struct Tile {
         F = F_new > F ? F_new : F;
     }
     // start of DMA block `blk` (T iterations of `step` rows each)
+    // Guard rows: ring slots [0, guard) copied to slots [R, R + guard) once the DMA that filled them has
+    // landed, every lane its own column.  A lane's rows of one symbol (at most guard - 1 rows apart) then
+    // lie at consecutive LDS addresses even when they wrap: one address and immediate offsets instead of a
+    // masked address per row.  [lo, hi) = the rows that have just landed.
+    __device__ __forceinline__ void mirror(int lo, int hi)
+    {
+        if (!guard || hi <= lo) return;
+        const int s0 = lo & RM;
+        if (s0 >= guard && s0 + (hi - lo) <= R) return;          // the range touches no slot below `guard`
+        typedef __attribute__((address_space(3))) IN lds_in;
+        lds_in *base = (lds_in *)(size_t)lds_base + lane;
+        IN v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = base[j * 64];
+#pragma unroll
+        for (int j = 0; j < 8; j++) base[(R + j) * 64] = v[j];
+    }
     __device__ __forceinline__ void advance(int blk, int step, int T, int C, int nwait)
     {
         if (blk > 0) wait_vmcnt(nwait);     // the previous block's DMA has landed
+        mirror(win_hi, F);
         win_hi = F;
         issue(step * (blk + 2) * T + C);
         win_lo = F - R > 0 ? F - R : 0;
@@ -316,6 +335,7 @@ struct Tile {
     {
         issue(step * T + C);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        mirror(0, F);
         win_hi = F;
     }
 };
@@ -526,7 +546,7 @@ __device__ __forceinline__ d2v pick3(unsigned lt, unsigned gt, d2v a, d2v b, d2v
     return r;
 }
 
-template <typename IN, bool SC, int MASK>
+template <typename IN, bool SC, int MASK, bool GUARD>
 __device__ __forceinline__ bool g2_spec_segment(const Tile<IN> &tl, dspm::GState &gs, const TimingConst &tc,
                                                 const int n, const int it0, const int roff, const SpecBases &sb,
                                                 const unsigned lane_s, const unsigned lane_c, const unsigned q_addr)
@@ -565,14 +585,29 @@ __device__ __forceinline__ bool g2_spec_segment(const Tile<IN> &tl, dspm::GState
         w_cur = (unsigned)(r_a - win_lo);
         ev_mu = (unsigned)__double2hiint(mu) & 0x7fffffffu;                // NaN counts as too large
         const unsigned rb = (unsigned)r_a * ROWB;
-        e0 = lds_ld<IN>((rb & rmask) | colb);
-        e1 = lds_ld<IN>(((rb + ROWB) & rmask) | colb);
-        m0 = lds_ld<IN>(((rb + midb) & rmask) | colb);
-        m1 = lds_ld<IN>(((rb + midb + ROWB) & rmask) | colb);
-        lm = lds_ld<IN>(((rb + lateb - ROWB) & rmask) | colb);
-        l0 = lds_ld<IN>(((rb + lateb) & rmask) | colb);
-        l1 = lds_ld<IN>(((rb + lateb + ROWB) & rmask) | colb);
-        l2 = lds_ld<IN>(((rb + lateb + 2u * ROWB) & rmask) | colb);
+        if (GUARD) {
+            // guard rows behind the ring (Tile::mirror): the rows of one symbol are contiguous in LDS, one
+            // masked address and immediate offsets (the compiler pairs them into ds_read2st64)
+            const unsigned a0 = (rb & rmask) | colb;
+            const unsigned am = a0 + midb, al = a0 + lateb;
+            e0 = lds_ld<IN>(a0);
+            e1 = lds_ld<IN>(a0 + ROWB);
+            m0 = lds_ld<IN>(am);
+            m1 = lds_ld<IN>(am + ROWB);
+            lm = lds_ld<IN>(al - ROWB);
+            l0 = lds_ld<IN>(al);
+            l1 = lds_ld<IN>(al + ROWB);
+            l2 = lds_ld<IN>(al + 2u * ROWB);
+        } else {
+            e0 = lds_ld<IN>((rb & rmask) | colb);
+            e1 = lds_ld<IN>(((rb + ROWB) & rmask) | colb);
+            m0 = lds_ld<IN>(((rb + midb) & rmask) | colb);
+            m1 = lds_ld<IN>(((rb + midb + ROWB) & rmask) | colb);
+            lm = lds_ld<IN>(((rb + lateb - ROWB) & rmask) | colb);
+            l0 = lds_ld<IN>(((rb + lateb) & rmask) | colb);
+            l1 = lds_ld<IN>(((rb + lateb + ROWB) & rmask) | colb);
+            l2 = lds_ld<IN>(((rb + lateb + 2u * ROWB) & rmask) | colb);
+        }
     };
 
     issue();
@@ -826,7 +861,7 @@ __device__ __forceinline__ void tile_init(Tile<IN> &tl, const SyncParams &P, uns
     tl.ring = ring;
     tl.lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)ring;
     tl.lane = lane; tl.col = lane; tl.R = P.ring_rows; tl.RM = P.ring_rows - 1; tl.in_rows = P.in_rows;
-    tl.win_lo = 0; tl.win_hi = 0; tl.F = 0; tl.scale = scale;
+    tl.win_lo = 0; tl.win_hi = 0; tl.F = 0; tl.scale = scale; tl.guard = P.guard_rows;
 }
 
 __device__ __forceinline__ void timing_init(TimingConst &tc, dspm::GState &gs, const SyncParams &P,
@@ -1036,7 +1071,7 @@ __global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
     const size_t obase = (size_t)tile * out_rows * 64 + lane;
     const bool ring = P.use_ring != 0;
 
-    unsigned char *q_base = smem + (size_t)P.ring_rows * 64 * sizeof(IN) * (ring ? 1 : 0);
+    unsigned char *q_base = smem + (size_t)(P.ring_rows + P.guard_rows) * 64 * sizeof(IN) * (ring ? 1 : 0);
     d2v *q_data = (d2v *)q_base;                                    // [2][TQ][64]
     unsigned char *q_flag = q_base + (size_t)2 * TQ * 64 * sizeof(d2v);   // [2][TQ][64]
     // explicit LDS pointer: a generic (flat) access would have to wait for vmcnt(0) as well
@@ -1167,14 +1202,27 @@ __global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
                     const unsigned qa = q_lds + (unsigned)(buf * TQ + tq) * 1024u;
                     DSP_TR(trp, 10);
                     DSP_TT(tt_e);
-                    switch (tmask) {
-                        case 7: seg_done = g2_spec_segment<IN, SC, 7>(tl, gs, tc, n, it, ROFF, sbases, lane_s, lane_c, qa); break;
-                        case 15: seg_done = g2_spec_segment<IN, SC, 15>(tl, gs, tc, n, it, ROFF, sbases, lane_s, lane_c, qa); break;
-                        case 12: seg_done = g2_spec_segment<IN, SC, 12>(tl, gs, tc, n, it, ROFF, sbases, lane_s, lane_c, qa); break;
-                        case 4: seg_done = g2_spec_segment<IN, SC, 4>(tl, gs, tc, n, it, ROFF, sbases, lane_s, lane_c, qa); break;
-                        case 0: seg_done = g2_spec_segment<IN, SC, 0>(tl, gs, tc, n, it, ROFF, sbases, lane_s, lane_c, qa); break;
-                        default: seg_done = g2_spec_segment<IN, SC, -1>(tl, gs, tc, n, it, ROFF, sbases, lane_s, lane_c, qa); break;
+#define DSP_SEG(M, G) seg_done = g2_spec_segment<IN, SC, M, G>(tl, gs, tc, n, it, ROFF, sbases, lane_s, lane_c, qa)
+                    if (tl.guard) {
+                        switch (tmask) {
+                            case 7: DSP_SEG(7, true); break;
+                            case 15: DSP_SEG(15, true); break;
+                            case 12: DSP_SEG(12, true); break;
+                            case 4: DSP_SEG(4, true); break;
+                            case 0: DSP_SEG(0, true); break;
+                            default: DSP_SEG(-1, true); break;
+                        }
+                    } else {
+                        switch (tmask) {
+                            case 7: DSP_SEG(7, false); break;
+                            case 15: DSP_SEG(15, false); break;
+                            case 12: DSP_SEG(12, false); break;
+                            case 4: DSP_SEG(4, false); break;
+                            case 0: DSP_SEG(0, false); break;
+                            default: DSP_SEG(-1, false); break;
+                        }
                     }
+#undef DSP_SEG
                     DSP_TR(trp, 11);
                     DSP_TT(tt_b);
                     if (seg_done) {
