@@ -26,6 +26,7 @@ struct dsp_ctx {
     int batch_split;    // 1 (default): a batch of more tiles than the CUs keep resident goes out as several launches
     int queue_block;    // split kernel: symbols per hand-off block, 0 = automatic
     int lead_copy;      // segment-parallel mode, warm-up rows: 0 = the filter's second store, 1 = seg_lead_copy_k, 2 = filtered per window
+    int dma_fll;        // split kernel: the FLL wave issues the ring's DMA (1, default) or the timing wave itself (0)
     int guard;          // split kernel: guard rows behind the LDS ring where they fit (1, default) or never (0)
     int spec;           // split kernel, linear interpolator: speculative branch-free segments (1, default) or the per-symbol votes (0)
     int spare_wave;     // split kernel, idle waves for SIMD balance: -1 auto, 0 never, 1 three waves, 2 four waves + CU tickets
@@ -246,6 +247,7 @@ int dsp_create(int device_id, dsp_ctx **out)
     c->spare_wave = -1;
     c->spec = 1;
     c->guard = 1;
+    c->dma_fll = 1;
     c->lead_copy = 0;
     c->fir_stream = 2;
     c->corr_window = 1;
@@ -374,6 +376,8 @@ int dsp_set_option(dsp_ctx *c, const char *name, int64_t value)
     } else if (!strcmp(name, "lead_copy")) {
         if (value < 0 || value > 2) return fail(DSP_E_ARG, "lead_copy must be 0, 1 or 2");
         c->lead_copy = (int)value;
+    } else if (!strcmp(name, "dma_fll")) {
+        c->dma_fll = value != 0;
     } else if (!strcmp(name, "guard")) {
         c->guard = value != 0;
     } else if (!strcmp(name, "spec")) {
@@ -723,6 +727,8 @@ static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, c
             }
         }
         P.TQ = TQ;
+        P.dma_fll = (c->dma_fll != 0 && c->spec && P.use_ring && a->variant == DSP_GARDNER2 && P.half_len == 0 &&
+                     P.T % TQ == 0) ? 1 : 0;
         // From three tiles per CU on two or more waves share a SIMD and the arbiter's oldest-first choice lets
         // some run ahead while others starve; rotating the four priority levels over the wave slots every 8
         // DMA blocks evens that out (65 536 bursts 1.93 -> 1.87 ms, 98 304 2.91 -> 2.52 ms; nothing at up

@@ -52,6 +52,8 @@ struct SyncParams {
                               // run: bit 31 set, XCC_ID in bits 19:16, HW_ID[15:0] (wave, SIMD 5:4, CU 11:8, SH 12, SE 15:13)
     int guard_rows;           // LDS rows behind the ring that mirror its first rows (0 or 8): a lane's rows of one symbol
                               // are then contiguous in LDS even across the ring's wrap (speculative segments)
+    int dma_fll;              // split kernel: the FLL wave (which idles a third of its time) issues the ring's LDS-DMA,
+                              // waits for it and mirrors the guard rows; needs T % TQ == 0 (sync_kernels.hip)
     int spec;                 // split kernel, gardner2 with the linear interpolator: speculative segments (sync_kernels.hip)
     int prio_period;          // split kernel: rotate the wave priority every this many DMA blocks (power of 2, 0 = off)
 #ifdef DSP_TRACE

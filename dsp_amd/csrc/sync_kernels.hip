@@ -331,6 +331,21 @@ struct Tile {
         issue(step * (blk + 2) * T + C);
         win_lo = F - R > 0 ? F - R : 0;
     }
+    // the same bookkeeping when another wave issues and awaits the DMA (SyncParams::dma_fll)
+    __device__ __forceinline__ void advance_nodma(int blk, int step, int T, int C)
+    {
+        win_hi = F;
+        int F_new = step * (blk + 2) * T + C;
+        F_new = F_new < in_rows ? F_new : in_rows;
+        F = F_new > F ? F_new : F;
+        win_lo = F - R > 0 ? F - R : 0;
+    }
+    __device__ __forceinline__ void prologue_nodma(int step, int T, int C)
+    {
+        const int F_new = step * T + C;
+        F = F_new < in_rows ? F_new : in_rows;
+        win_hi = F;
+    }
     __device__ __forceinline__ void prologue(int step, int T, int C)
     {
         issue(step * T + C);
@@ -1136,7 +1151,13 @@ __global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
         // =================== timing wave ===================
         Tile<IN> tl;
         tile_init(tl, P, smem, tile, lane, scale);
-        if (ring) tl.prologue(sps, T, P.C);
+        const bool dma_fll = ring && P.dma_fll != 0;    // the FLL wave feeds the ring (see its side below)
+        if (dma_fll) {
+            asm volatile("s_barrier" ::: "memory");     // B0: the first block's rows have landed
+            tl.prologue_nodma(sps, T, P.C);
+        } else if (ring) {
+            tl.prologue(sps, T, P.C);
+        }
         TimingConst tc;
         dspm::GState gs;
         timing_init(tc, gs, P, VARIANT, len, lane_ok, b);
@@ -1184,7 +1205,8 @@ __global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
             if (prio_n && --prio_c == 0) { prio_c = prio_n; rotate_priority(slot, ++prio_ph); }
             DSP_TR(trp, 0);
             DSP_TT(tt_d);
-            if (ring) tl.advance(blk, sps, T, P.C, P.nwait);
+            if (dma_fll) tl.advance_nodma(blk, sps, T, P.C);
+            else if (ring) tl.advance(blk, sps, T, P.C, P.nwait);
             DSP_TT(tt_a);
             DSP_TR(trp, 9);
             // the steady path's stores address a row by a 32-bit byte offset from the tile's base: a
@@ -1316,6 +1338,25 @@ __global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
         const dspm::MathK MK = load_math_consts();
         OC *o_sig = (OC *)P.sig; OS *o_freq = (OS *)P.freq; OS *o_ef = (OS *)P.ef;
         uint8_t *o_dec = P.dec;
+        // dma_fll: this wave feeds the timing wave's ring.  It waits at the hand-over barriers a third of its
+        // time (the timing wave is the longer chain), and issuing a DMA block costs the issuing wave ~70 cycles
+        // per KiB, so the producer role moves here: with block b of the timing loop = queue blocks
+        // [b k, (b + 1) k), k = T / TQ, the rows of block b + 1 are awaited (vmcnt over this wave's own stores
+        // since the issue, counted at run time) and their guard rows mirrored BEFORE the barrier that ends
+        // block b, and the rows of block b + 2 are issued right AFTER it -- the moments at which the timing
+        // wave did both itself.  B0 hands over block 0.
+        const bool dma_fll = ring && P.dma_fll != 0;
+        const int n_fst = (o_sig ? 1 : 0) + (o_freq ? 1 : 0) + (o_ef ? 1 : 0) + (o_dec ? 1 : 0);
+        const int kq = T / TQ;
+        Tile<IN> tf;
+        int landed = 0, nst = 0;
+        if (dma_fll) {
+            tile_init(tf, P, smem, tile, lane, 1.0);
+            tf.prologue(sps, T, P.C);
+            landed = tf.F;
+            tf.issue(sps * 2 * T + P.C);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // B0
+        }
         if (VARIANT == DSP_VARIANT_GARDNER2) {       // recovered[0] = signal[0]
             const bool have = (lane_ok || pass) && len > 0;
             IN v = xt[src];
@@ -1325,6 +1366,7 @@ __global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
             if (o_freq) st_val(o_freq + obase, fo.freq);
             if (o_ef) st_val(o_ef + obase, fo.ef);
             if (o_dec) st_b8(o_dec + obase, fo.quad);
+            nst += n_fst;
         }
         int it = 0;
         prio_n = prio_n ? (prio_n * T / TQ > 0 ? prio_n * T / TQ : 1) : 0;     // same period in queue blocks
@@ -1342,8 +1384,20 @@ __global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
             if (prio_n && --prio_c == 0) { prio_c = prio_n; rotate_priority(slot, ++prio_ph); }
             DSP_TR(trp, 5);
             DSP_TT(tt_d);
+            const bool dma_edge = dma_fll && (qb + 1) % kq == 0;    // this barrier ends a block of the timing loop
+            if (dma_edge) {
+                wait_vmcnt(nst);                                    // every DMA issued so far has landed
+                tf.mirror(landed, tf.F);
+                landed = tf.F;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            DSP_TT(tt_a);
             asm volatile("s_barrier" ::: "memory");
             DSP_TT(tt_c);
+            if (dma_edge) {
+                tf.issue(sps * ((qb + 1) / kq + 2) * T + P.C);
+                nst = 0;
+            }
             DSP_TR(trp, 0);
             const unsigned qa0 = q_lds + (unsigned)(buf * TQ) * 1024u;
             const int qfl = q_more[buf];
@@ -1362,6 +1416,7 @@ __global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
                 }
                 DSP_TR(trp, 12);
                 DSP_TT(tt_b);
+                nst += TQ * n_fst;                       // (a block that failed its vote is stored again below)
                 if (blk_done) it += TQ;
             }
             if (!blk_done) {
@@ -1379,6 +1434,7 @@ __global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
                         if (o_freq) st_val(o_freq + off, fo.freq);
                         if (o_ef) st_val(o_ef + off, fo.ef);
                         if (o_dec) st_b8(o_dec + off, fo.quad);
+                        nst += n_fst;
                     }
                     DSP_TR(trp, 5);
                 }
