@@ -26,6 +26,7 @@ struct dsp_ctx {
     int batch_split;    // 1 (default): a batch of more tiles than the CUs keep resident goes out as several launches
     int queue_block;    // split kernel: symbols per hand-off block, 0 = automatic
     int lead_copy;      // segment-parallel mode, warm-up rows: 0 = the filter's second store, 1 = seg_lead_copy_k, 2 = filtered per window
+    int prio_role;      // split kernel: timing waves above FLL waves (1), rotation / none (0), -1 = automatic
     int dma_fll;        // split kernel: the FLL wave issues the ring's DMA (1, default) or the timing wave itself (0)
     int guard;          // split kernel: guard rows behind the LDS ring where they fit (1, default) or never (0)
     int spec;           // split kernel, linear interpolator: speculative branch-free segments (1, default) or the per-symbol votes (0)
@@ -248,6 +249,7 @@ int dsp_create(int device_id, dsp_ctx **out)
     c->spec = 1;
     c->guard = 1;
     c->dma_fll = 1;
+    c->prio_role = -1;
     c->lead_copy = 0;
     c->fir_stream = 2;
     c->corr_window = 1;
@@ -376,6 +378,8 @@ int dsp_set_option(dsp_ctx *c, const char *name, int64_t value)
     } else if (!strcmp(name, "lead_copy")) {
         if (value < 0 || value > 2) return fail(DSP_E_ARG, "lead_copy must be 0, 1 or 2");
         c->lead_copy = (int)value;
+    } else if (!strcmp(name, "prio_role")) {
+        c->prio_role = (int)value;
     } else if (!strcmp(name, "dma_fll")) {
         c->dma_fll = value != 0;
     } else if (!strcmp(name, "guard")) {
@@ -570,14 +574,15 @@ static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, c
         return fail(DSP_E_ARG, "sync: interp_half_len must be in [0,8]");
     if (fll && !(a->y > 0.0)) return fail(DSP_E_ARG, "sync: y must be > 0");
 
-    // More tiles than a CU keeps resident (the two-wave kernel's 133 VGPRs allow six two-wave tiles): the
-    // surplus would run as a second, poorly filled round (131 072 bursts: 4.8 ms against 2 x 1.93).  Such a
-    // batch goes out as equal launches of whole tiles instead, each of at most six tiles per CU; the bursts
-    // are independent, so only the pointers move.  (Occupancy beyond four tiles per CU buys nothing: the
-    // launch is HBM-bound from there.)
+    // More tiles than a CU keeps resident (as far as the kernel's registers go: four two-wave tiles at the
+    // linear kernel's 192 VGPRs, read from the code object): the surplus would run as a second, poorly filled
+    // round (98 304 bursts: 4.4 ms against 2 x 1.4).  Such a batch goes out as equal launches of whole tiles
+    // instead, each of at most that many tiles per CU; the bursts are independent, so only the pointers move.
     {
         const int64_t ntiles_all = (a->B + 63) / 64;
-        const int64_t resident = (int64_t)c->n_cu * 6;
+        const int per_cu_max = (fll && a->variant != 2 && a->interp_half_len == 0)
+                                   ? sync_split_tiles_per_cu(a->dtype == DSP_C128, a->variant, a->scale != nullptr) : 4;
+        const int64_t resident = (int64_t)c->n_cu * per_cu_max;
         if (ntiles_all > resident && c->batch_split != 0) {
             const int64_t nlaunch = (ntiles_all + resident - 1) / resident;
             int64_t per = (ntiles_all + nlaunch - 1) / nlaunch;                   // tiles per launch ...
@@ -734,6 +739,8 @@ static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, c
         // DMA blocks evens that out (65 536 bursts 1.93 -> 1.87 ms, 98 304 2.91 -> 2.52 ms; nothing at up
         // to two tiles per CU, where every wave has a SIMD to itself).  Scheduling only: same bits.
         P.prio_period = c->prio_period >= 0 ? c->prio_period : (per_cu >= 3 ? 8 : 0);
+        P.prio_role = c->prio_role > 0 ? 1 : 0;
+        if (P.prio_role) P.prio_period = 0;
         // two 2-wave workgroups per CU land on three SIMDs (sync_kernels.hip); the idle middle wave
         // spreads them over four.  Measured: 512 tiles 1.57 -> 1.30 ms; no gain at one workgroup per
         // CU, 3 % slower at three or four, and at eight the spare waves cost occupancy

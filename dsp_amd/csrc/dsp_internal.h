@@ -52,6 +52,7 @@ struct SyncParams {
                               // run: bit 31 set, XCC_ID in bits 19:16, HW_ID[15:0] (wave, SIMD 5:4, CU 11:8, SH 12, SE 15:13)
     int guard_rows;           // LDS rows behind the ring that mirror its first rows (0 or 8): a lane's rows of one symbol
                               // are then contiguous in LDS even across the ring's wrap (speculative segments)
+    int prio_role;            // split kernel: fixed wave priority by role, timing wave (the longer chain) above the FLL wave
     int dma_fll;              // split kernel: the FLL wave (which idles a third of its time) issues the ring's LDS-DMA,
                               // waits for it and mirrors the guard rows; needs T % TQ == 0 (sync_kernels.hip)
     int spec;                 // split kernel, gardner2 with the linear interpolator: speculative segments (sync_kernels.hip)
@@ -68,6 +69,7 @@ struct SyncPlan { int use_ring, ring_rows, T, C, nwait, lds_bytes; };
 SyncPlan sync_plan(int elem_bytes, int sps, int half_len, int variant, int n_store, int ring_rows_req);
 hipError_t launch_sync(const SyncParams &P, bool c128, int variant, bool fll, size_t lds_bytes,
                        hipStream_t stream);
+int sync_split_tiles_per_cu(bool c128, int variant, bool scaled);
 
 // tiling: burst-major [B][ld] <-> tiles
 hipError_t launch_tile_from_bursts(const void *src, int64_t ld, const int *lens, int len_all, int B,

@@ -1042,8 +1042,11 @@ __device__ __forceinline__ unsigned wave_slot()
 //   fills the other half.  Every block both waves execute exactly one barrier.
 // NWV = waves launched per tile: 2, or 3 / 4 with idle waves for the dispatcher (below); separate
 // instantiations so that the plain launch compiles exactly as it did without them (0.9 % at B = 65 536)
+#ifndef DSP_SPLIT_MIN_WAVES
+#define DSP_SPLIT_MIN_WAVES 1
+#endif
 template <typename IN, int VARIANT, bool SC, int NWV, int H = 0>
-__global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
+__global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void sync_split_kernel(SyncParams P)
 {
     typedef typename InT<IN>::OS OS;
     typedef typename InT<IN>::OC OC;
@@ -1124,6 +1127,9 @@ __global__ __launch_bounds__(64 * NWV) void sync_split_kernel(SyncParams P)
     }
     const unsigned slot = wave_slot();
     int prio_n = P.prio_period, prio_c = 1, prio_ph = 0;
+    if (P.prio_role) {                                  // (role is wave-uniform)
+        if (role == 0) asm volatile("s_setprio 3"); else asm volatile("s_setprio 0");
+    }
     // coarse timers of the trace build, kept in registers (the stamps build's TrAcc lives in scratch memory
     // and every stamp waits for vmcnt(0): with LDS-DMA in flight that measures the DMA, not the code)
 #if defined(DSP_TRACE) && !defined(DSP_TRACE_STAMPS)
@@ -1604,6 +1610,24 @@ static hipError_t launch_in(const SyncParams &P, int variant, bool fll, size_t l
             return launch_v<IN, DSP_VARIANT_NONE, true>(P, lds, s);
     }
     return hipErrorInvalidValue;
+}
+
+// Two-wave tiles of the linear-interpolator kernel a CU can hold as far as its registers go: read from the
+// code object (the speculative segments raised the kernel from 133 to 192 VGPRs, i.e. from six tiles per CU
+// to four -- a number that must not live in the host code as a constant).
+int sync_split_tiles_per_cu(bool c128, int variant, bool scaled)
+{
+    void (*k)(SyncParams);
+    if (c128) k = variant == DSP_VARIANT_GARDNER2 ? (scaled ? sync_split_kernel<d2v, DSP_VARIANT_GARDNER2, true, 2> : sync_split_kernel<d2v, DSP_VARIANT_GARDNER2, false, 2>)
+                                                  : (scaled ? sync_split_kernel<d2v, DSP_VARIANT_TED, true, 2> : sync_split_kernel<d2v, DSP_VARIANT_TED, false, 2>);
+    else k = variant == DSP_VARIANT_GARDNER2 ? (scaled ? sync_split_kernel<f2v, DSP_VARIANT_GARDNER2, true, 2> : sync_split_kernel<f2v, DSP_VARIANT_GARDNER2, false, 2>)
+                                             : (scaled ? sync_split_kernel<f2v, DSP_VARIANT_TED, true, 2> : sync_split_kernel<f2v, DSP_VARIANT_TED, false, 2>);
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, (const void *)k) != hipSuccess) { (void)hipGetLastError(); return 4; }
+    const int regs = (fa.numRegs + 7) & ~7;                      // allocated in blocks of eight
+    const int waves = regs > 0 ? 512 / regs : 8;                 // per SIMD, 512 VGPRs each
+    const int tiles = (waves > 8 ? 8 : waves) * 4 / 2;           // four SIMDs, two waves per tile
+    return tiles < 1 ? 1 : tiles;
 }
 
 hipError_t launch_sync(const SyncParams &P, bool c128, int variant, bool fll, size_t lds_bytes,
