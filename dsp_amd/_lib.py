@@ -149,6 +149,9 @@ def _declare(L):
     L.dsp_cfo_fourth_power.argtypes = [vp, vp, ci, i64, i64, i64, vp, i64, vp]
     L.dsp_derotate.argtypes = [vp, vp, ci, i64, vp, i64, i64, vp, vp, vp, i64]
     L.dsp_cfo_derotate_dev.argtypes = [vp, vp, ci, i64, vp, i64, i64, ci, vp, ci, ci, vp, vp]
+    L.dsp_rx_front_dev.argtypes = [vp, vp, ci, i64, vp, i64, i64, ci, vp, ci, ci, vp, vp, ci, vp, i64, vp, vp, vp, i64]
+    L.dsp_rx_front_workspace_bytes.argtypes = [i64, i64]
+    L.dsp_rx_front_workspace_bytes.restype = i64
     L.dsp_rx_bursts.argtypes = [vp, vp, ci, i64, vp, i64, i64, vp, ci, ci, vp, vp, ci, ci, ci, dbl, dbl, ci, ci,
                                 dbl, dbl, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp]
     L.dsp_fll_class.argtypes = [vp, vp, ci, i64, i64, i64, vp, ci, dbl, dbl, dbl, vp, vp, vp, vp, i64, vp]
@@ -164,7 +167,7 @@ def _declare(L):
                  "dsp_untile_dev", "dsp_sync_tiles_dev", "dsp_load_iq_i16", "dsp_load_iq_f32",
                  "dsp_fir_same_std", "dsp_rx_chain", "dsp_fir_tiles_dev", "dsp_synth_bursts_dev",
                  "dsp_sync_capture_segmented", "dsp_sync_capture_segmented_dev", "dsp_synth_stream_dev", "dsp_lagrange_resample", "dsp_fll_class", "dsp_diff_corr",
-                 "dsp_cfo_preamble", "dsp_cfo_fourth_power", "dsp_derotate", "dsp_rx_bursts", "dsp_cfo_derotate_dev", "dsp_fll_slicer", "dsp_trim",
+                 "dsp_cfo_preamble", "dsp_cfo_fourth_power", "dsp_derotate", "dsp_rx_bursts", "dsp_cfo_derotate_dev", "dsp_rx_front_dev", "dsp_fll_slicer", "dsp_trim",
                  "dsp_device_info", "dsp_capture_validate", "dsp_fir_tiles_static_dev"):
         getattr(L, name).restype = ci
 

@@ -26,6 +26,7 @@ struct dsp_ctx {
     int batch_split;    // 1 (default): a batch of more tiles than the CUs keep resident goes out as several launches
     int queue_block;    // split kernel: symbols per hand-off block, 0 = automatic
     int lead_copy;      // segment-parallel mode, warm-up rows: 0 = the filter's second store, 1 = seg_lead_copy_k, 2 = filtered per window
+    int fuse_derot;     // dsp_rx_bursts: cut + derotation inside the matched filter's staging (1, default) or as a pass of its own (0)
     int prio_role;      // split kernel: timing waves above FLL waves (1), rotation / none (0), -1 = automatic
     int dma_fll;        // split kernel: the FLL wave issues the ring's DMA (1, default) or the timing wave itself (0)
     int guard;          // split kernel: guard rows behind the LDS ring where they fit (1, default) or never (0)
@@ -250,6 +251,7 @@ int dsp_create(int device_id, dsp_ctx **out)
     c->guard = 1;
     c->dma_fll = 1;
     c->prio_role = -1;
+    c->fuse_derot = 1;
     c->lead_copy = 0;
     c->fir_stream = 2;
     c->corr_window = 1;
@@ -378,6 +380,8 @@ int dsp_set_option(dsp_ctx *c, const char *name, int64_t value)
     } else if (!strcmp(name, "lead_copy")) {
         if (value < 0 || value > 2) return fail(DSP_E_ARG, "lead_copy must be 0, 1 or 2");
         c->lead_copy = (int)value;
+    } else if (!strcmp(name, "fuse_derot")) {
+        c->fuse_derot = value != 0;
     } else if (!strcmp(name, "prio_role")) {
         c->prio_role = (int)value;
     } else if (!strcmp(name, "dma_fll")) {
@@ -1082,6 +1086,97 @@ static int fir_stage(dsp_ctx *c, FirStage &S, const void *x, int in_kind, int64_
     return dsp_fir_tiles_dev(c, &a);
 }
 
+// cut + derotation + matched filter (+ statistics) in one pass over the signal: launches only.  *fused = false
+// (nothing launched) when the shape is not the fused kernels' -- more than FIR_MT taps, "fir_stream" 0.
+static int fir_derot_run(dsp_ctx *c, const void *d_x, int dtype, const int64_t *d_off, const double *d_f, int f_stride,
+                         int64_t B, int64_t N, const double *d_h, int n_taps, void *d_tiles, int64_t rows, double *d_std,
+                         double *d_inv, void *ws, int64_t ws_bytes, bool *fused)
+{
+    *fused = false;
+    FirParams P;
+    memset(&P, 0, sizeof(P));
+    P.src = d_x; P.src_off = d_off; P.derot_f = d_f; P.derot_fstride = f_stride;
+    P.ld = N; P.len_all = (int)N; P.B = (int)B; P.M = n_taps; P.start = (n_taps - 1) / 2;
+    P.strip_ok = c->fir_stream == 2; P.n_cu = c->n_cu;
+    P.dst = d_tiles; P.rows = (int)rows;
+    if (c->fir_stream == 0 || !fir_plan_derot(P, dtype)) return DSP_OK;
+    const bool want_std = d_std || d_inv;
+    if (want_std && (!ws || ws_bytes < B * (P.nchunk + 8) * 32))
+        return fail(DSP_E_ARG, "rx_front: workspace too small (need %lld bytes, have %lld)",
+                    (long long)B * (P.nchunk + 8) * 32, (long long)ws_bytes);
+    P.h = d_h; P.h_pad = c->fir_taps;
+    P.stats = want_std ? (double *)ws : nullptr;
+    HIP_TRY(launch_fir_derot(P, dtype, c->stream));
+    if (want_std) HIP_TRY(launch_fir_stats_finish(P, d_std, d_inv, c->stream));
+    *fused = true;
+    return DSP_OK;
+}
+
+// ... with the buffers of a FirStage (dsp_rx_bursts)
+static int fir_stage_derot(dsp_ctx *c, FirStage &S, const void *d_x, int dtype, const int64_t *d_off, const double *d_f,
+                           int f_stride, int64_t B, int64_t N, const double *h, int n_taps, bool want_std, bool *fused)
+{
+    hipStream_t s = c->stream;
+    *fused = false;
+    if (c->fir_stream == 0 || n_taps > DSP_FIR_MT) return DSP_OK;
+    S.rows = dsp_tile_rows(N);
+    const int64_t ntiles = (B + 63) / 64;
+    const int64_t wsb = dsp_rx_front_workspace_bytes(B, N);
+    HIP_TRY(S.d_h.alloc((size_t)n_taps * 8));
+    HIP_TRY(hipMemcpyAsync(S.d_h.p, h, (size_t)n_taps * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(S.d_tiles.alloc((size_t)ntiles * S.rows * 64 * 16));
+    HIP_TRY(hipMemsetAsync(S.d_tiles.p, 0, (size_t)ntiles * S.rows * 64 * 16, s));
+    HIP_TRY(S.d_std.alloc((size_t)B * 8));
+    HIP_TRY(S.d_inv.alloc((size_t)B * 8));
+    HIP_TRY(S.d_ws.alloc((size_t)wsb));
+    return fir_derot_run(c, d_x, dtype, d_off, d_f, f_stride, B, N, S.d_h.as<double>(), n_taps, S.d_tiles.p, S.rows,
+                         want_std ? S.d_std.as<double>() : nullptr, want_std ? S.d_inv.as<double>() : nullptr, S.d_ws.p, wsb,
+                         fused);
+}
+
+int64_t dsp_rx_front_workspace_bytes(int64_t B, int64_t n_pkt)
+{
+    FirParams P;
+    if (B < 1 || n_pkt < 1 || n_pkt > 0x7fffffff || !fir_plan(DSP_IN_C128, DSP_FIR_MT, (int)n_pkt, P, true, true)) return 0;
+    return B * (P.nchunk + 8) * 32;
+}
+
+// device-resident front end of dsp_rx_bursts, fused: frequency (estimated or given), then cut + derotation +
+// matched filter + std in ONE pass over the signal.  Asynchronous.
+int dsp_rx_front_dev(dsp_ctx *c, const void *d_x, int dtype, int64_t n, const int64_t *d_offsets, int64_t B,
+                     int64_t n_pkt, int sps, const double *d_preamble_c128, int n_pre, int cfo_method, double *d_f,
+                     const double *d_h, int n_taps, void *d_tiles_c128, int64_t rows, double *d_std, double *d_inv_std,
+                     void *workspace, int64_t workspace_bytes)
+{
+    if (!c) return fail(DSP_E_ARG, "ctx is NULL");
+    if (dtype != DSP_C64 && dtype != DSP_C128) return fail(DSP_E_ARG, "rx_front: dtype must be DSP_C64 or DSP_C128");
+    if (!d_x || !d_offsets || !d_f || !d_h) return fail(DSP_E_ARG, "rx_front: NULL argument");
+    if (B < 1 || B > 0x7fffffff || n_pkt < 1 || n_pkt > n || n_pkt > 0x7fffffff || sps < 1)
+        return fail(DSP_E_ARG, "rx_front: bad sizes");
+    if (n_taps < 1 || n_taps > n_pkt) return fail(DSP_E_ARG, "rx_front: 1 <= n_taps <= n_pkt");
+    if (n_taps > DSP_FIR_MT || c->fir_stream == 0)
+        return fail(DSP_E_ARG, "rx_front: the fused kernels take at most %d taps (dsp_cfo_derotate_dev + dsp_fir_tiles_dev "
+                    "for longer filters)", DSP_FIR_MT);
+    if (d_tiles_c128 && rows < n_pkt) return fail(DSP_E_ARG, "rx_front: rows < n_pkt");
+    if (cfo_method < 0 || cfo_method > 3) return fail(DSP_E_ARG, "rx_front: cfo_method is 0 or 1..3");
+    if (cfo_method != 0 && (!d_preamble_c128 || n_pre < 2 || n_pre > 4096 || (int64_t)(n_pre - 1) * sps + 1 > n_pkt))
+        return fail(DSP_E_ARG, "rx_front: the preamble needs 2..4096 symbols inside the packet");
+    HIP_TRY(hipSetDevice(c->device));
+    int f_stride = 1;
+    const double *d_fsel = d_f;
+    if (cfo_method != 0) {
+        HIP_TRY(launch_cfo_preamble(d_x, dtype == DSP_C128, d_offsets, (int)B, sps, d_preamble_c128, n_pre, d_f, c->stream));
+        d_fsel = d_f + (cfo_method - 1);
+        f_stride = 3;
+    }
+    bool fused = false;
+    int rc = fir_derot_run(c, d_x, dtype, d_offsets, d_fsel, f_stride, B, n_pkt, d_h, n_taps, d_tiles_c128, rows, d_std,
+                           d_inv_std, workspace, workspace_bytes, &fused);
+    if (rc != DSP_OK) return rc;
+    if (!fused) return fail(DSP_E_ARG, "rx_front: shape not supported by the fused kernels");
+    return DSP_OK;
+}
+
 int dsp_fir_same_std(dsp_ctx *c, const void *x, int dtype, int64_t B, int64_t N, int64_t x_stride,
                      const int32_t *lens, const double *h, int n_taps, int start, int normalize_std,
                      void *y, int64_t y_stride, double *std_out)
@@ -1440,7 +1535,6 @@ int dsp_rx_bursts(dsp_ctx *c, const void *x, int dtype, int64_t n, const int64_t
     hipStream_t s = c->stream;
     DevBuf d_x, d_o, d_p, d_f, d_cut;
     HIP_TRY(d_x.alloc((size_t)n * eb)); HIP_TRY(d_o.alloc((size_t)B * 8)); HIP_TRY(d_f.alloc((size_t)B * 24));
-    HIP_TRY(d_cut.alloc((size_t)B * n_pkt * 16));
     HIP_TRY(hipMemcpyAsync(d_x.p, x, (size_t)n * eb, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_o.p, offsets, (size_t)B * 8, hipMemcpyHostToDevice, s));
     if (cfo_method == 0) {
@@ -1449,9 +1543,9 @@ int dsp_rx_bursts(dsp_ctx *c, const void *x, int dtype, int64_t n, const int64_t
         HIP_TRY(d_p.alloc((size_t)n_pre * 16));
         HIP_TRY(hipMemcpyAsync(d_p.p, preamble_c128, (size_t)n_pre * 16, hipMemcpyHostToDevice, s));
     }
-    rc = dsp_cfo_derotate_dev(c, d_x.p, dtype, n, d_o.as<int64_t>(), B, n_pkt, sps, d_p.as<double>(), n_pre,
-                              cfo_method, d_f.as<double>(), d_cut.as<double>());
-    if (rc != DSP_OK) return rc;
+    if (cfo_method != 0)
+        HIP_TRY(launch_cfo_preamble(d_x.p, dtype == DSP_C128, d_o.as<int64_t>(), (int)B, sps, d_p.as<double>(), n_pre,
+                                    d_f.as<double>(), s));
     const int f_stride = cfo_method == 0 ? 1 : 3;
     const double *d_fsel = d_f.as<double>() + (cfo_method == 0 ? 0 : cfo_method - 1);
     if (f_rel_out) {
@@ -1461,10 +1555,23 @@ int dsp_rx_bursts(dsp_ctx *c, const void *x, int dtype, int64_t n, const int64_t
             HIP_TRY(hipMemcpy2DAsync(f_rel_out, 8, d_fsel, 24, 8, (size_t)B, hipMemcpyDeviceToHost, s));
         }
     }
+    // cut + derotation (worker.py:287,298-299) ride in the matched filter's staging loads where its LDS-tiled
+    // kernels apply -- the signal is read once and the derotated bursts never exist in memory -- and are a pass
+    // of their own in front of it otherwise (long filters; "fuse_derot" 0).  Same arithmetic, same bits.
     FirStage S;
     const bool want_std = normalize_std || std_out;
-    rc = fir_stage(c, S, d_cut.p, DSP_C128, B, n_pkt, n_pkt, nullptr, 0, h, n_taps, -1, want_std, false, true);
-    if (rc != DSP_OK) return rc;
+    bool fused = false;
+    if (c->fuse_derot) {
+        rc = fir_stage_derot(c, S, d_x.p, dtype, d_o.as<int64_t>(), d_fsel, f_stride, B, n_pkt, h, n_taps, want_std, &fused);
+        if (rc != DSP_OK) return rc;
+    }
+    if (!fused) {
+        HIP_TRY(d_cut.alloc((size_t)B * n_pkt * 16));
+        HIP_TRY(launch_derotate_cut(d_x.p, dtype == DSP_C128, d_o.as<int64_t>(), nullptr, d_fsel, f_stride, (int)B, n_pkt,
+                                    d_cut.p, n_pkt, s));
+        rc = fir_stage(c, S, d_cut.p, DSP_C128, B, n_pkt, n_pkt, nullptr, 0, h, n_taps, -1, want_std, false, true);
+        if (rc != DSP_OK) return rc;
+    }
     if (std_out) HIP_TRY(hipMemcpyAsync(std_out, S.d_std.p, (size_t)B * 8, hipMemcpyDeviceToHost, s));
     return sync_to_host(c, S.d_tiles.p, DSP_C128, B, n_pkt, S.rows, nullptr,
                         normalize_std ? S.d_inv.as<double>() : nullptr, sps, alpha, mu0, variant,

@@ -87,6 +87,16 @@ struct FirParams {
     int64_t ld;               // samples between consecutive bursts (may be < N: overlapping views)
     const int *lens;          // [B] or NULL -> len_all
     int len_all, B;
+    // bursts cut out of one signal: burst b, sample n is src[src_off[b] + n] (NULL -> src[b * ld + n]); outside
+    // [0, len) the filter sees zeros (np.convolve on the cut burst), not the signal's neighbours
+    const int64_t *src_off;
+    // cut + derotation fused into the staging loads (worker.py:298-299): sample n of burst b is multiplied by
+    // exp(-1j * fl(fl(2 pi * f_b) * (n + i0_b))) in float64 as it goes to LDS, f_b = derot_f[b * derot_fstride],
+    // i0_b = derot_i0 ? derot_i0[b] : src_off[b]; the filter then runs on complex128 staging whatever the
+    // input type.  NULL -> no derotation.  fir_stream_kernel / fir_strip_kernel only (<= 41 taps).
+    const double *derot_f;
+    int derot_fstride;
+    const int64_t *derot_i0;
     // windows of ONE long stream (segment-parallel mode): burst b, sample n is stream sample
     // starts[b] + n, present iff 0 <= starts[b] + n < n_total (so the filter sees the true
     // neighbours across window edges and zeros only beyond the stream's own ends)
@@ -124,7 +134,12 @@ struct FirParams {
 
 bool fir_plan(int in_kind, int M, int n_out, FirParams &P, bool allow_stream = true, bool c128_stream = false);
 bool fir_try_c128_strips(FirParams &P);       // complex128: switch a filled P to the strip kernel's plan if it applies
+#define DSP_FIR_MT 41          // taps the stream / strip kernels are unrolled for (fir_kernels.hip)
 hipError_t launch_fir_tile(FirParams &P, int in_kind, hipStream_t s);
+// the fused form (P.derot_f, P.src_off set; in_kind DSP_IN_C64 or DSP_IN_C128; output complex128 tiles): plans
+// the stream / strip kernels over float64 staging; false -> the shape needs the unfused path
+bool fir_plan_derot(FirParams &P, int in_kind);
+hipError_t launch_fir_derot(FirParams &P, int in_kind, hipStream_t s);
 // stream_mode requested: can fir_strip_kernel serve these parameters?  (false: clears stream_mode; the
 // caller falls back to the overlapping-window pass)
 bool fir_stream_mode_plan(FirParams &P, int in_kind);

@@ -31,6 +31,40 @@ __device__ __forceinline__ f2v to_stage(s2v v, float isc) { return f2v{(float)v.
 __device__ __forceinline__ f2v to_stage(f2v v, float) { return v; }
 __device__ __forceinline__ d2v to_stage(d2v v, float) { return v; }
 
+// XF = 1: cut + derotation fused into the staging (FirParams::derot_f): float64 staging whatever the input
+// type, every sample multiplied by exp(-1j theta) on its way to LDS -- the arithmetic of derotate_cut_kernel
+// (cfo_kernels.hip) expression for expression, so the filtered bursts are the same bits as filtering its output.
+template <typename IN, int XF> struct StageT { typedef typename Stage<IN>::T T; };
+template <typename IN> struct StageT<IN, 1> { typedef d2v T; };
+template <typename IN, int XF> struct RowX {                 // per-burst input transform
+    float isc;
+    __device__ __forceinline__ void init(const FirParams &, int, float isc_) { isc = isc_; }
+    __device__ __forceinline__ typename Stage<IN>::T operator()(IN v, int) const { return to_stage(v, isc); }
+};
+template <typename IN> struct RowX<IN, 1> {
+    double w;
+    int64_t i0;
+    __device__ __forceinline__ void init(const FirParams &P, int b, float)
+    {
+        b = b < P.B ? b : P.B - 1;
+        w = 6.283185307179586 * P.derot_f[(size_t)b * P.derot_fstride];          // (2 pi) * f_rel, then * n
+        i0 = P.derot_i0 ? P.derot_i0[b] : P.src_off[b];
+    }
+    __device__ __forceinline__ d2v operator()(IN v, int n) const
+    {
+        const double th = w * (double)((int64_t)n + i0);
+        double sn, cs;
+        sincos(th, &sn, &cs);
+        const double xr = (double)v.x, xi = (double)v.y;
+        return d2v{xr * cs + xi * sn, xi * cs - xr * sn};                        // x * (cos - j sin)
+    }
+};
+// first sample of burst b in the source
+__device__ __forceinline__ int64_t burst_origin(const FirParams &P, int b)
+{
+    return P.src_off ? P.src_off[b < P.B ? b : P.B - 1] : (int64_t)b * P.ld;
+}
+
 // (nontemporal: the tiles are read next by another kernel, long after they left the caches; 2.17 -> 2.14 ms per pass)
 __device__ __forceinline__ void put(f2v *p, double re, double im) { __builtin_nontemporal_store(f2v{(float)re, (float)im}, p); }
 __device__ __forceinline__ void put(d2v *p, double re, double im) { *p = d2v{re, im}; }
@@ -38,11 +72,11 @@ __device__ __forceinline__ void put(d2v *p, double re, double im) { *p = d2v{re,
 // Stage the input windows of one tile: xs[bb][i] = x[b][x0 + i], i < W, zero outside the burst (or the
 // stream).  W <= 64 * KS, so a wave covers a row in KS steps; all loads of a wave are issued before
 // the first LDS write (each wave would otherwise pay the HBM latency once per load).
-template <typename IN, int KS, int NW>
-__device__ __forceinline__ void stage_windows(const FirParams &P, typename Stage<IN>::T *xs, int tile, int x0, int W,
+template <typename IN, int KS, int NW, int XF = 0>
+__device__ __forceinline__ void stage_windows(const FirParams &P, typename StageT<IN, XF>::T *xs, int tile, int x0, int W,
                                               int stride, float isc, int lane, int w)
 {
-    typedef typename Stage<IN>::T ST;
+    typedef typename StageT<IN, XF>::T ST;
     constexpr int RQ = 64 / NW;                        // rows a wave stages
     // Interior chunks of full tiles need no bounds logic at all (it is half of the kernel's instructions
     // otherwise): every staged index of all 64 rows lies inside its burst, or inside the stream (window
@@ -57,7 +91,7 @@ __device__ __forceinline__ void stage_windows(const FirParams &P, typename Stage
 #pragma unroll
         for (int q = 0; q < RQ; q++) {
             const int b = tile * 64 + w * RQ + q;
-            const IN *src = P.starts ? (const IN *)P.src + (P.starts[b] + x0) : (const IN *)P.src + ((int64_t)b * P.ld + x0);
+            const IN *src = P.starts ? (const IN *)P.src + (P.starts[b] + x0) : (const IN *)P.src + (burst_origin(P, b) + x0);
 #pragma unroll
             for (int k = 0; k < KS; k++) {
                 int i = lane + 64 * k;
@@ -68,11 +102,13 @@ __device__ __forceinline__ void stage_windows(const FirParams &P, typename Stage
 #pragma unroll
         for (int q = 0; q < RQ; q++) {
             ST *row = xs + (size_t)(w * RQ + q) * stride;
+            RowX<IN, XF> rx;
+            rx.init(P, tile * 64 + w * RQ + q, isc);
 #pragma unroll
             for (int k = 0; k < KS; k++) {
                 const int i = lane + 64 * k;
-                if (64 * (k + 1) <= W) row[i] = to_stage(v[q][k], isc);
-                else if (i < W) row[i] = to_stage(v[q][k], isc);
+                if (64 * (k + 1) <= W) row[i] = rx(v[q][k], x0 + i);
+                else if (i < W) row[i] = rx(v[q][k], x0 + i);
             }
         }
     } else {
@@ -94,7 +130,7 @@ __device__ __forceinline__ void stage_windows(const FirParams &P, typename Stage
                 }
             } else {
                 const int len = live ? (P.lens ? P.lens[b] : P.len_all) : 0;
-                const IN *src = (const IN *)P.src + (int64_t)(live ? b : 0) * P.ld;
+                const IN *src = (const IN *)P.src + burst_origin(P, live ? b : 0);
 #pragma unroll
                 for (int k = 0; k < KS; k++) {
                     const int i = lane + 64 * k, n = x0 + i;
@@ -105,10 +141,12 @@ __device__ __forceinline__ void stage_windows(const FirParams &P, typename Stage
         }
 #pragma unroll
         for (int q = 0; q < RQ; q++) {
+            RowX<IN, XF> rx;
+            rx.init(P, tile * 64 + w * RQ + q, isc);
 #pragma unroll
             for (int k = 0; k < KS; k++) {
                 const int i = lane + 64 * k;
-                if (i < W) xs[(size_t)(w * RQ + q) * stride + i] = ok[q][k] ? to_stage(v[q][k], isc) : ST{0, 0};
+                if (i < W) xs[(size_t)(w * RQ + q) * stride + i] = ok[q][k] ? rx(v[q][k], x0 + i) : ST{0, 0};
             }
         }
     }
@@ -335,7 +373,7 @@ __global__ __launch_bounds__(64 * NW) void fir_tile_kernel(FirParams P)
 //     all loads and conversions to the top and needs 220 VGPRs).
 // Each output's sum runs over the samples in ascending order, as in fir_tile_kernel.
 constexpr int FIR_STREAM_OG = 14;   // outputs per lane and wave of the stream kernel (chunk = 8 waves x 14 = 112)
-constexpr int FIR_MT = 41;      // taps the stream kernel is unrolled for (shorter filters are zero padded)
+constexpr int FIR_MT = DSP_FIR_MT;     // taps the stream kernel is unrolled for (shorter filters are zero padded)
 constexpr int FIR_GS = 4;       // window samples per scheduling group
 
 typedef const __attribute__((address_space(4))) double *cdbl_ptr;     // constant address space: scalar loads
@@ -389,10 +427,10 @@ __global__ void fir_pad_taps_k(const double *__restrict__ h, int M, double *__re
     if (i < FIR_MT) out[i] = i < M ? h[i] : 0.0;
 }
 
-template <typename IN, typename OUT, int OG, int KS, int NW>
+template <typename IN, typename OUT, int OG, int KS, int NW, int XF = 0>
 __global__ __launch_bounds__(64 * NW) void fir_stream_kernel(FirParams P)
 {
-    typedef typename Stage<IN>::T ST;
+    typedef typename StageT<IN, XF>::T ST;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int CH = OG * NW, W = CH + FIR_MT - 1;
     const int stride = P.stride;
@@ -413,7 +451,7 @@ __global__ __launch_bounds__(64 * NW) void fir_stream_kernel(FirParams P)
     const float isc = P.in_scale ? *P.in_scale : 1.0f;
     // the filter as FIR_MT taps, zeros appended: y[n] = sum_{j < FIR_MT} h[j] x[n + start - j]
     const int x0 = n0 + P.start - (FIR_MT - 1);
-    stage_windows<IN, KS, NW>(P, xs, tile, x0, W, stride, isc, lane, w);
+    stage_windows<IN, KS, NW, XF>(P, xs, tile, x0, W, stride, isc, lane, w);
     __syncthreads();
 
     LaneOut<OUT> lo;
@@ -472,10 +510,11 @@ __device__ __forceinline__ d2v wide_get(const Wide<d2v>::T &v, int) { return d2v
 // complex128 input (the drop-in path's sample type) stages float64 pairs: 150 KB of LDS, one workgroup per
 // CU with up to 256 VGPRs, two loads per lane for a row's new samples -- that shape is HBM-bound (32 bytes
 // per sample in and out), not fp64-bound.
-template <typename IN, typename OUT, int OG, bool SCALED, bool STORE, bool STREAM = false>
-__global__ __launch_bounds__(512, sizeof(typename Stage<IN>::T) == 16 ? 2 : 4) void fir_strip_kernel(FirParams P)
+template <typename IN, typename OUT, int OG, bool SCALED, bool STORE, bool STREAM = false, int XF = 0>
+__global__ __launch_bounds__(512, sizeof(typename StageT<IN, XF>::T) == 16 ? 2 : 4) void fir_strip_kernel(FirParams P)
 {
-    typedef typename Stage<IN>::T ST;
+    static_assert(!(STREAM && XF), "the capture's segments are not derotated");
+    typedef typename StageT<IN, XF>::T ST;
     typedef typename Wide<IN>::T WV;
     constexpr int NW = 8, RQ = 64 / NW, CH = OG * NW, HALO = FIR_MT - 1, W = CH + HALO;
     constexpr int SPL = Wide<IN>::SPL;                  // samples per load
@@ -493,9 +532,16 @@ __global__ __launch_bounds__(512, sizeof(typename Stage<IN>::T) == 16 ? 2 : 4) v
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float isc = P.in_scale ? *P.in_scale : 1.0f;
     const cdbl_ptr hp = (cdbl_ptr)P.h_pad;
-    // the RQ rows (bursts) this wave loads, as one wave-uniform base
+    // the RQ rows (bursts) this wave loads, as one wave-uniform base (XF: each row's own origin in the signal)
     const IN *rows0 = (const IN *)P.src + (int64_t)(tile * 64 + w * RQ) * P.ld + P.start - HALO;
+    auto row_src = [&](int q) {                                               // sample 0 of row q
+        if constexpr (XF != 0) return (const IN *)P.src + P.src_off[tile * 64 + w * RQ + q];
+        else return rows0 + (int64_t)q * P.ld + HALO - P.start;
+    };
     ST *myrows = xs + w * RQ * stride;
+    RowX<IN, XF> rx[RQ];
+#pragma unroll
+    for (int q = 0; q < RQ; q++) rx[q].init(P, tile * 64 + w * RQ + q, isc);
 
     // this lane's burst: output row pointer, scale, statistics
     const int ntiles = gridDim.y;
@@ -517,7 +563,7 @@ __global__ __launch_bounds__(512, sizeof(typename Stage<IN>::T) == 16 ? 2 : 4) v
         const int g0 = c_lo * CH + P.start - HALO;      // burst sample of the window's first sample
 #pragma unroll
         for (int q = 0; q < RQ; q++) {
-            const IN *src = rows0 + (int64_t)q * P.ld + HALO - P.start;        // the row's sample 0
+            const IN *src = row_src(q);                                        // the row's sample 0
             const int64_t row_at = (int64_t)row_burst(q) * P.ld;               // ... as a stream sample
 #pragma unroll
             for (int k = 0; k < NPL; k++) {
@@ -542,7 +588,7 @@ __global__ __launch_bounds__(512, sizeof(typename Stage<IN>::T) == 16 ? 2 : 4) v
                 if (i < WPR) {
 #pragma unroll
                     for (int u = 0; u < SPL; u++)
-                        myrows[q * stride + i * SPL + u] = in ? to_stage(wide_get(v[q][k], u), isc) : ST{0, 0};
+                        myrows[q * stride + i * SPL + u] = in ? rx[q](wide_get(v[q][k], u), g + u) : ST{0, 0};
                 }
             }
         }
@@ -573,8 +619,7 @@ __global__ __launch_bounds__(512, sizeof(typename Stage<IN>::T) == 16 ? 2 : 4) v
                     const int lim = room > 0x7fffffff ? 0x7fffffff : (int)room;
                     pre[q][j] = __builtin_nontemporal_load((const WV *)((const IN *)P.src + row_at + (gn[j] > lim ? lim : gn[j])));
                 } else {
-                    const IN *src = rows0 + (int64_t)q * P.ld + HALO - P.start;
-                    pre[q][j] = __builtin_nontemporal_load((const WV *)(src + g));
+                    pre[q][j] = __builtin_nontemporal_load((const WV *)(row_src(q) + g));
                 }
             }
         }
@@ -639,7 +684,7 @@ __global__ __launch_bounds__(512, sizeof(typename Stage<IN>::T) == 16 ? 2 : 4) v
                     for (int q = 0; q < RQ; q++) {
 #pragma unroll
                         for (int u = 0; u < SPL; u++)
-                            myrows[q * stride + HALO + piece * SPL + u] = to_stage(wide_get(pre[q][j], u), isc);
+                            myrows[q * stride + HALO + piece * SPL + u] = rx[q](wide_get(pre[q][j], u), gn[j] + u);
                     }
                 } else {
 #pragma unroll
@@ -648,7 +693,7 @@ __global__ __launch_bounds__(512, sizeof(typename Stage<IN>::T) == 16 ? 2 : 4) v
                                                : (gn[j] + SPL <= len);
 #pragma unroll
                         for (int u = 0; u < SPL; u++)
-                            myrows[q * stride + HALO + piece * SPL + u] = in ? to_stage(wide_get(pre[q][j], u), isc) : ST{0, 0};
+                            myrows[q * stride + HALO + piece * SPL + u] = in ? rx[q](wide_get(pre[q][j], u), gn[j] + u) : ST{0, 0};
                     }
                 }
             }
@@ -893,25 +938,28 @@ __global__ void iq_i16_convert_kernel(const s2v *__restrict__ raw, int64_t n, co
         out[i] = f2v{(float)raw[i].x * s, (float)raw[i].y * s};
 }
 
-template <typename IN, typename OUT>
+template <typename IN, typename OUT, int XF = 0>
 hipError_t launch_fir_stream_t(const FirParams &P, hipStream_t s)
 {
     constexpr int OG = FIR_STREAM_OG, NW = 8, CH = OG * NW, W = CH + FIR_MT - 1, KS = (W + 63) / 64;
     if (P.CH != CH || P.W != W || !P.h_pad) return hipErrorInvalidValue;
+    if (XF ? (!P.derot_f || !P.src_off || P.stream_mode || P.starts) : (P.derot_f != nullptr)) return hipErrorInvalidValue;
     const int ntiles = (P.B + 63) / 64;
-    size_t lds = (size_t)64 * P.stride * sizeof(typename Stage<IN>::T);            // 78 KB, 153 KB for complex128
+    size_t lds = (size_t)64 * P.stride * sizeof(typename StageT<IN, XF>::T);       // 78 KB, 153 KB for complex128
     if (lds < (size_t)NW * 64 * 4 * 8) lds = (size_t)NW * 64 * 4 * 8;              // the statistics scratch
     hipLaunchKernelGGL(fir_pad_taps_k, dim3(1), dim3(64), 0, s, P.h, P.M, P.h_pad);
-    void (*k)(FirParams) = fir_stream_kernel<IN, OUT, OG, KS, NW>;
+    void (*k)(FirParams) = fir_stream_kernel<IN, OUT, OG, KS, NW, XF>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
     if (P.cps > 0) {
         // strips over the interior chunks of the full tiles ...
-        void (*ks)(FirParams) = P.dst ? (P.scale ? fir_strip_kernel<IN, OUT, OG, true, true> : fir_strip_kernel<IN, OUT, OG, false, true>)
-                                      : fir_strip_kernel<IN, OUT, OG, false, false>;
-        if (P.stream_mode) ks = fir_strip_kernel<IN, OUT, OG, false, true, true>;     // capture mode: unscaled, stored
+        void (*ks)(FirParams) = P.dst ? (P.scale ? fir_strip_kernel<IN, OUT, OG, true, true, false, XF>
+                                                 : fir_strip_kernel<IN, OUT, OG, false, true, false, XF>)
+                                      : fir_strip_kernel<IN, OUT, OG, false, false, false, XF>;
+        if constexpr (XF == 0)
+            if (P.stream_mode) ks = fir_strip_kernel<IN, OUT, OG, false, true, true>; // capture mode: unscaled, stored
         hipError_t e = hipFuncSetAttribute((const void *)ks, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         // 78 KB of LDS and <= 128 VGPRs: two workgroups per CU, so that one's load / barrier phases fall
@@ -1004,7 +1052,10 @@ static void fir_plan_strips(FirParams &P, int in_kind)
     const int spl = in_kind == DSP_IN_C128 ? 1 : 2;                    // samples per load (Wide<IN>)
     const int esz = in_kind == DSP_IN_I16 ? 4 : in_kind == DSP_IN_C128 ? 16 : 8;
     const int piece = spl * esz;                                       // bytes per load: 8 or 16
-    if (P.ld % spl || (P.start - (FIR_MT - 1)) % spl || ((uintptr_t)P.src % piece) || (P.ld * esz) % piece) return;
+    if ((P.start - (FIR_MT - 1)) % spl) return;
+    // bursts cut at arbitrary samples (src_off) start on a sample, not on a piece: global loads need only
+    // the element's own alignment, and the pieces are counted from each burst's first sample
+    if (!P.src_off && (P.ld % spl || ((uintptr_t)P.src % piece) || (P.ld * esz) % piece)) return;
     if (P.len_all % spl || P.rows < P.len_all || P.start < 0) return;   // the bursts' ends fall between two loads' pieces
     // (the stream may end anywhere inside the B segments, on a 16-byte piece: a cut segment and empty ones
     //  behind it are zeros to the filter and left out of its statistics)
@@ -1059,8 +1110,39 @@ bool fir_try_c128_strips(FirParams &P)
     return true;
 }
 
+// cut + derotation + filter in one pass (FirParams::derot_f): the stream / strip kernels over float64
+// staging, output complex128 tiles
+bool fir_plan_derot(FirParams &P, int in_kind)
+{
+    if (in_kind != DSP_IN_C64 && in_kind != DSP_IN_C128) return false;
+    if (!P.derot_f || !P.src_off || P.M > FIR_MT || P.lens || P.starts || P.stream_mode || P.in_scale) return false;
+    FirParams T = P;
+    if (!fir_plan(DSP_IN_C128, P.M, P.len_all, T, true, true) || !T.stream) return false;
+    P.stream = 1; P.CH = T.CH; P.W = T.W; P.stride = T.stride; P.nchunk = T.nchunk;
+    // The statistics are merged strip by strip or chunk by chunk, and np.std's last bit follows the grouping:
+    // the fused pass must group as the two-pass form does (complex128 bursts of their own, one sample per
+    // load).  Without strips the two-pass form runs fir_tile_kernel's chunks (fewer than 64 bursts, fewer than
+    // 8 chunks); complex64 signals load two samples at a time and lose the strips when the packet length or
+    // the filter's start is odd -- those shapes stay with the two passes.
+    FirParams A = P, C = P;
+    fir_plan_strips(A, in_kind);
+    C.src = nullptr; C.src_off = nullptr; C.derot_f = nullptr; C.ld = P.len_all;
+    fir_plan_strips(C, DSP_IN_C128);
+    return C.cps > 0 && A.cps == C.cps && A.strip_tiles == C.strip_tiles;
+}
+
+hipError_t launch_fir_derot(FirParams &P, int in_kind, hipStream_t s)
+{
+    if (!P.stream || !P.derot_f || !P.src_off) return hipErrorInvalidValue;
+    fir_plan_strips(P, in_kind);               // samples per load of the INPUT type; float64 staging either way
+    if (in_kind == DSP_IN_C64) return launch_fir_stream_t<f2v, d2v, 1>(P, s);
+    if (in_kind == DSP_IN_C128) return launch_fir_stream_t<d2v, d2v, 1>(P, s);
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_fir_tile(FirParams &P, int in_kind, hipStream_t s)
 {
+    if (P.derot_f || P.src_off) return hipErrorInvalidValue;    // launch_fir_derot's
     const int want_stream_mode = P.stream_mode;
     fir_plan_strips(P, in_kind);
     if (want_stream_mode && (!P.cps || !P.stream_mode)) return hipErrorInvalidValue;   // see fir_stream_mode_plan

@@ -277,11 +277,26 @@ int dsp_derotate(dsp_ctx *ctx, const void *x, int dtype, int64_t n, const int64_
 /* Device-resident front end of dsp_rx_bursts (asynchronous on the context's stream; every pointer is
  * device memory): frequency per burst estimated from the preamble (cfo_method 1..3: d_f is [B][3] and
  * receives all three estimates) or taken from d_f [B] (cfo_method 0), then out[b][i] = x[off_b + i] *
- * exp(-1j 2 pi f_b (i + off_b)), complex128 [B][n_pkt] -- ready for dsp_fir_tiles_dev (DSP_IN_C128).
+ * exp(-1j 2 pi f_b (i + off_b)), complex128 [B][n_pkt] -- ready for dsp_fir_tiles_dev (DSP_C128).
  * The offsets are the caller's responsibility here: 0 <= off_b and off_b + n_pkt <= n.            */
 int dsp_cfo_derotate_dev(dsp_ctx *ctx, const void *d_x, int dtype, int64_t n, const int64_t *d_offsets, int64_t B,
                          int64_t n_pkt, int sps, const double *d_preamble_c128, int n_pre, int cfo_method,
                          double *d_f, double *d_out_c128);
+
+/* The same front end with the matched filter behind it, as ONE pass over the signal (worker.py:287-299:
+ * cut, f_rel, derotation, filter_samples): the estimator runs as above, then every sample is cut out of the
+ * signal, derotated and filtered on its way through LDS -- the derotated bursts never exist in memory.
+ * Results are the bits of dsp_cfo_derotate_dev followed by dsp_fir_tiles_dev (DSP_C128) on its output.
+ * d_h: n_taps <= 41 float64 taps on the device ("same" alignment, start = (n_taps - 1) / 2).
+ * d_tiles_c128: complex128 tiles, `rows` >= n_pkt rows per tile (dsp_tile_rows), or NULL (statistics only).
+ * d_std / d_inv_std: [B] np.std of each filtered burst and its reciprocal, or NULL; they need `workspace`
+ * of dsp_rx_front_workspace_bytes(B, n_pkt) bytes.  Longer filters: DSP_E_ARG (use the two calls above).
+ * Asynchronous on the context's stream.                                                              */
+int64_t dsp_rx_front_workspace_bytes(int64_t B, int64_t n_pkt);
+int dsp_rx_front_dev(dsp_ctx *ctx, const void *d_x, int dtype, int64_t n, const int64_t *d_offsets, int64_t B,
+                     int64_t n_pkt, int sps, const double *d_preamble_c128, int n_pre, int cfo_method, double *d_f,
+                     const double *d_h, int n_taps, void *d_tiles_c128, int64_t rows, double *d_std,
+                     double *d_inv_std, void *workspace, int64_t workspace_bytes);
 
 /* The per-burst body of worker.Processing.process (worker.py:284-304) for B bursts of one signal in
  * one call: coarse CFO from the preamble (cfo_method 1..3 as above; 0 = take f_rel_in), cut of n_pkt
