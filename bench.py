@@ -96,7 +96,7 @@ def launch(n, argv, timeout=900, script=None):
 
 
 # ---------------------------------------------------------------------------
-def capture_mode(ctx, log2_samples=30, warmup=4096):
+def capture_mode(ctx, log2_samples=30, warmup=2048):
     """Informational (BASELINE.json configs[5]): ONE int16 IQ capture of 2^30 samples, generated on the
     device, through the segment-parallel receiver (peak, RRC + whole-stream std, Gardner + FLL over the
     windows, stitching); the second call is timed with HIP events, the decisions of the first 2^18 symbols
@@ -120,7 +120,7 @@ def capture_mode(ctx, log2_samples=30, warmup=4096):
         assert abs(nsym - int(round(n * (1.0 + drift) / SPS))) <= 4 and rate > 0.999, (nsym, rate)
         return {"workload": f"one int16 IQ capture of 2^{log2_samples} samples (4 sps QPSK, RRC 0.35, CFO 1.5e-4, "
                             f"drifting timing, Es/N0 20 dB), segment-parallel: seg_len {pipe.seg_len}, "
-                            f"warm-up {warmup} symbols, decisions + mu out",
+                            f"warm-up {warmup} symbols from a fractional feed-forward start, decisions + mu out",
                 "segments": pipe.S, "symbols": nsym, "ms": ms, "Msamples_per_s": n / ms / 1e3,
                 "symbol_match_rate": rate}
     finally:

@@ -355,8 +355,8 @@ def auto_seg_len(n, sps, warmup):
 
 
 def sync_capture_segmented(x, sps=4, alpha=0.007, mu_initial=0.0, Bn=0.003, y=1, *, taps=None,
-                           seg_len=None, warmup=4096, normalize=True, want=("dec", "mu", "freq"),
-                           acquire=True, ctx=None):
+                           seg_len=None, warmup=2048, normalize=True, want=("dec", "mu", "freq"),
+                           acquire=2, ctx=None):
     """Segment-parallel Gardner + FLL + decisions over ONE long capture (no reference
     counterpart; north-star (c), include/dsp_hip.h dsp_sync_capture_segmented).
 
@@ -371,8 +371,11 @@ def sync_capture_segmented(x, sps=4, alpha=0.007, mu_initial=0.0, Bn=0.003, y=1,
     deviations of the loop's own estimate noise after a 4096-symbol warm-up at Bn = 0.003, more when
     the warm-up is shorter than the loop's settling time.  Decisions and mu carry over.
     seg_len: samples per segment, a multiple of sps (None: auto_seg_len).
-    acquire (default): every window starts its timing loop at the sampling phase whose strobes carry
-    the most energy over its first 256 symbols (mu_initial is then unused); False: at mu_initial.
+    acquire: 2 (default): every window starts its timing loop at the fractional phase of the
+    symbol-rate line of |x|^2 over its first 512 symbols, within some 0.01 sample rms of the lock point
+    (a 2048-symbol warm-up then leaves < 3e-4 symbol against one sequential loop); 1 / True: at the
+    sampling phase whose strobes carry the most energy over its first 256 symbols (up to half a sample
+    off: 4096 warm-up symbols for the same); 0 / False: at mu_initial.
     """
     ctx = ctx or default_context()
     x = np.asarray(x)
@@ -404,7 +407,7 @@ def sync_capture_segmented(x, sps=4, alpha=0.007, mu_initial=0.0, Bn=0.003, y=1,
         h = np.ascontiguousarray(taps, dtype=np.float64)
         a.h = h.ctypes.data; a.n_taps = h.size
     a.sps = int(sps); a.alpha = float(alpha); a.mu0 = float(mu_initial); a.Bn = float(Bn); a.y = float(y)
-    a.seg_len = int(seg_len); a.warmup = int(warmup); a.acquire = int(bool(acquire))
+    a.seg_len = int(seg_len); a.warmup = int(warmup); a.acquire = int(acquire)
     a.dec = dec.ctypes.data
     a.mu = mu.ctypes.data if mu is not None else None
     a.freq = freq.ctypes.data if freq is not None else None

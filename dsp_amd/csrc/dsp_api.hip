@@ -44,6 +44,8 @@ struct dsp_ctx {
     // gigabytes: hipMalloc / hipFree per call cost milliseconds); released by dsp_trim / dsp_destroy
     void *scratch[8];
     size_t scratch_bytes[8];
+    void *pinned;       // page-locked host block for the small results a call brings home (seg_info, counts)
+    size_t pinned_bytes;
 #ifdef DSP_TRACE
     unsigned long long *trace;
     int trace_stamps;
@@ -208,12 +210,29 @@ static hipError_t ctx_scratch(dsp_ctx *c, int slot, size_t n, void **p)
     return hipSuccess;
 }
 
+// page-locked host memory kept in the context: a device-to-host copy into it is one DMA, where a copy into
+// pageable memory is staged and blocks the host (0.1 ms for the 512 KB of a 2^30-sample capture's seg_info)
+static hipError_t ctx_pinned(dsp_ctx *c, size_t n, void **p)
+{
+    if (c->pinned_bytes < n) {
+        if (c->pinned) (void)hipHostFree(c->pinned);
+        c->pinned = nullptr; c->pinned_bytes = 0;
+        hipError_t e = hipHostMalloc(&c->pinned, n, hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        c->pinned_bytes = n;
+    }
+    *p = c->pinned;
+    return hipSuccess;
+}
+
 static void ctx_trim(dsp_ctx *c)
 {
     for (int i = 0; i < 8; i++) {
         if (c->scratch[i]) (void)hipFree(c->scratch[i]);
         c->scratch[i] = nullptr; c->scratch_bytes[i] = 0;
     }
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    c->pinned = nullptr; c->pinned_bytes = 0;
 }
 
 extern "C" {
@@ -1670,6 +1689,7 @@ int dsp_capture_validate(const dsp_capture_args *a)
     if (a->n_samples < 2 * a->sps) return fail(DSP_E_ARG, "capture: too few samples");
     if (a->seg_len < 16 * a->sps || a->seg_len % a->sps) return fail(DSP_E_ARG, "capture: seg_len must be a multiple of sps, >= 16 symbols");
     if (a->warmup < 0) return fail(DSP_E_ARG, "capture: negative warm-up");
+    if (a->acquire < 0 || a->acquire > 2) return fail(DSP_E_ARG, "capture: acquire is 0 (mu0), 1 (sample grid) or 2 (fractional)");
     if (a->h && (a->n_taps < 1 || a->n_taps > 4096)) return fail(DSP_E_ARG, "capture: bad n_taps");
     if (!(a->y > 0.0)) return fail(DSP_E_ARG, "capture: y must be > 0");
     if (dsp_capture_segments(a->n_samples, a->seg_len) > (1 << 24)) return fail(DSP_E_ARG, "capture: too many segments");
@@ -1822,8 +1842,9 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
 
     // ---- initial timing phase per window (strobe energy), unless the caller fixes mu0 ------------
     if (a->acquire) {
-        HIP_TRY(launch_seg_phase(win_x, (int)rows, d_lens.as<int>(), n_slots, sps, DSP_ACQUIRE_SYMBOLS,
-                                 d_mu0.as<double>(), st, win_stride, win_tile0));
+        HIP_TRY(launch_seg_phase(win_x, (int)rows, d_lens.as<int>(), n_slots, sps,
+                                 a->acquire == 2 ? DSP_ACQUIRE_FRAC_SYMBOLS : DSP_ACQUIRE_SYMBOLS,
+                                 d_mu0.as<double>(), st, win_stride, win_tile0, a->acquire == 2));
     }
 
     // ---- the batched recurrence over the windows -------------------------------------------
@@ -1851,11 +1872,13 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
     if (vote > 256) vote = 256;
     HIP_TRY(launch_seg_stitch(G, vote, st));
     HIP_TRY(launch_seg_gather(G, a->dec, a->mu, a->freq, a->capacity, st));
-    int64_t total = 0;
-    HIP_TRY(hipMemcpyAsync(&total, d_off.as<int64_t>() + n_slots, 8, hipMemcpyDeviceToHost, st));
+    // the count and seg_info come home through the context's page-locked block: [total | j0 | j1 | rot | n_out]
+    int64_t *h_total = nullptr;
+    HIP_TRY(ctx_pinned(c, 64 + (a->seg_info ? (size_t)Sa * 16 : 0), (void **)&h_total));
+    HIP_TRY(hipMemcpyAsync(h_total, d_off.as<int64_t>() + n_slots, 8, hipMemcpyDeviceToHost, st));
     if (a->seg_info) {
-        std::vector<int32_t> info((size_t)Sa * 4);           // [j0 | j1 | rot | n_out], Sa slots each
-        HIP_TRY(hipMemcpyAsync(info.data(), d_j0.p, (size_t)Sa * 16, hipMemcpyDeviceToHost, st));
+        const int32_t *info = (const int32_t *)((const char *)h_total + 64);      // Sa slots each
+        HIP_TRY(hipMemcpyAsync((void *)info, d_j0.p, (size_t)Sa * 16, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         for (size_t s = 0; s < (size_t)S; s++) {
             const size_t at = (size_t)seg_slot((int)s, map_tiles);           // the device arrays are in slot order
@@ -1864,6 +1887,7 @@ int dsp_sync_capture_segmented_dev(dsp_ctx *c, const dsp_capture_args *a)
         }
     }
     HIP_TRY(hipStreamSynchronize(st));
+    const int64_t total = *h_total;
     if (a->n_symbols) *a->n_symbols = total;
     if (total > a->capacity)
         return fail(DSP_E_CAPACITY, "capture: %lld symbols, capacity %lld", (long long)total, (long long)a->capacity);

@@ -205,7 +205,7 @@ hipError_t launch_seg_edge_tiles(void *tiles, int map_tiles, int64_t seg_len, in
                                  const int *lens, void *tile0, int win_rows, int pad_rows, hipStream_t s);
 hipError_t launch_seg_lead_copy(void *tiles, int rows, const int64_t *starts, int S, int lead, hipStream_t s);
 hipError_t launch_seg_phase(const void *tiles, int rows, const int *lens, int S, int sps, int n_sym, double *mu0,
-                            hipStream_t s, int x_tile_rows = 0, const void *x_tile0 = nullptr);
+                            hipStream_t s, int x_tile_rows = 0, const void *x_tile0 = nullptr, int frac = 0);
 hipError_t launch_seg_stitch(const SegParams &P, int overlap_vote, hipStream_t s);
 hipError_t launch_seg_gather(const SegParams &P, uint8_t *dec_out, float *mu_out, float *freq_out,
                              int64_t capacity, hipStream_t s);

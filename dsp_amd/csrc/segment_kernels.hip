@@ -126,16 +126,16 @@ __global__ __launch_bounds__(64) void seg_range_k(SegParams P, int vote_len)
         if (V > jp) V = jp;
         // every pair of decisions agrees under exactly one of the four turns: one pass, four counters
         int agree[4] = {0, 0, 0, 0};
-        for (int m0 = 0; m0 < V; m0 += 8) {                 // eight pairs of loads in flight
-            unsigned a[8], b[8];
+        for (int m0 = 0; m0 < V; m0 += 32) {                // 32 pairs of loads in flight (8: 98 us at 32768 windows)
+            unsigned a[32], b[32];
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
+            for (int i = 0; i < 32; i++) {
                 const int m = m0 + i < V ? m0 + i : V - 1;
                 a[i] = tile_u8(P.dec, P.out_rows, at, j0 - 1 - m);
                 b[i] = tile_u8(P.dec, P.out_rows, before, jp - 1 - m);
             }
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
+            for (int i = 0; i < 32; i++) {
                 if (m0 + i >= V) continue;
 #pragma unroll
                 for (int r4 = 0; r4 < 4; r4++) agree[r4] += rot_quadrant(a[i], r4) == b[i];
@@ -160,9 +160,16 @@ __global__ __launch_bounds__(1024) void seg_offsets_k(SegParams P)
     const int per = (P.S + 1023) / 1024;
     const int lo = t * per, hi = (lo + per < P.S) ? lo + per : P.S;
     long long c = 0; int r = 0;
-    for (int s = lo; s < hi; s++) {
-        const int at = seg_slot(s, P.map_tiles);
-        c += P.j1[at] - P.j0[at]; r += P.rot[at];
+    for (int s0 = lo; s0 < hi; s0 += 8) {                   // 24 loads in flight: the slots of a slice lie far apart
+        int a1[8], a0[8], ar[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int at = seg_slot(s0 + i < hi ? s0 + i : hi - 1, P.map_tiles);
+            a1[i] = P.j1[at]; a0[i] = P.j0[at]; ar[i] = P.rot[at];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (s0 + i < hi) { c += a1[i] - a0[i]; r += ar[i]; }
     }
     cnt[t] = c; rsum[t] = r;
     __syncthreads();
@@ -176,12 +183,21 @@ __global__ __launch_bounds__(1024) void seg_offsets_k(SegParams P)
     }
     if (t == 1023) P.off[P.n_slots] = cnt[1023];
     long long a = cnt[t] - c; int b = rsum[t] - r;         // exclusive: the sums in front of this thread's slice
-    for (int s = lo; s < hi; s++) {
-        const int at = seg_slot(s, P.map_tiles);
-        b += P.rot[at];                      // window s is turned by the sum of the relative turns up to s
-        P.off[at] = a;
-        a += P.j1[at] - P.j0[at];
-        P.rot[at] = b & 3;
+    for (int s0 = lo; s0 < hi; s0 += 8) {
+        int a1[8], a0[8], ar[8], at[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            at[i] = seg_slot(s0 + i < hi ? s0 + i : hi - 1, P.map_tiles);
+            a1[i] = P.j1[at[i]]; a0[i] = P.j0[at[i]]; ar[i] = P.rot[at[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (s0 + i >= hi) break;
+            b += ar[i];                      // window s is turned by the sum of the relative turns up to s
+            P.off[at[i]] = a;
+            a += a1[i] - a0[i];
+            P.rot[at[i]] = b & 3;
+        }
     }
 }
 
@@ -220,40 +236,81 @@ __global__ __launch_bounds__(256) void seg_lead_copy_k(float2 *__restrict__ tile
 // strobes x[p + k sps], k < n_sym, carry the most energy -- the spectral line of |x|^2 at the symbol
 // rate (Oerder-Meyr) read on the sample grid, at most half a sample from the lock point.  Lane =
 // window over the tiled filter output; sums in float64, in k order (the oracle adds in the same order).
-__global__ __launch_bounds__(512) void seg_phase_k(const float2 *__restrict__ tiles, int rows,
-                                                   const int *__restrict__ lens, int S, int sps, int n_sym,
-                                                   double *__restrict__ mu0, const float2 *__restrict__ tile0)
+// frac: the line's phase instead of its largest sample -- the energies E_p are samples of A + B cos(2 pi
+// (t - tau) / sps), so tau = atan2(sum E_p sin(2 pi p / sps), sum E_p cos(2 pi p / sps)) * sps / (2 pi) in
+// [0, sps), rounded to 1/1024 sample (which makes it the oracle's number whatever the last bits of atan2 and
+// of the table are).  Measured against the sequential loop's mu at that point: 0.013 sample rms over 512
+// symbols (0.29 for the sample grid), so the windows' loops have 1/20 of the distance to converge over.
+__device__ __forceinline__ double seg_phase_tau(double cs, double sn, int sps)
 {
-    // one wave per sampling phase (sps <= 8: the workgroup has sps waves), each adding its phase's
-    // strobes in k order, 8 loads in flight; wave 0 then takes the first maximum over the phases
-    __shared__ double e[8][64];
+    double tau = atan2(sn, cs) * (double)sps / 6.283185307179586;
+    if (tau < 0.0) tau += (double)sps;
+    const double q = floor(tau * 1024.0 + 0.5) / 1024.0;
+    return q >= (double)sps ? q - (double)sps : q;
+}
+__device__ __forceinline__ double seg_phase_pick(const double *e, int stride, int sps, int frac)
+{
+    if (!frac) {
+        double best = -1.0;
+        int arg = 0;
+        for (int p = 0; p < sps; p++)
+            if (e[p * stride] > best) { best = e[p * stride]; arg = p; }
+        return (double)arg;
+    }
+    double cs = 0.0, sn = 0.0;
+    for (int p = 0; p < sps; p++) {
+        const double t = (double)p / (double)sps;
+        cs += e[p * stride] * cospi(2.0 * t);               // exact at the quarter turns
+        sn += e[p * stride] * sinpi(2.0 * t);
+    }
+    return seg_phase_tau(cs, sn, sps);
+}
+
+// Waves per sampling phase: the fractional estimate reads twice the rows, so its strobes are summed in
+// `parts` contiguous parts of ceil(ns / parts) each (k order inside a part, the parts added first to last) by
+// as many waves -- part of its definition, the oracle adds the same way.  The sample grid's sum is one part.
+__host__ __device__ inline int seg_phase_parts(int sps, int frac) { return !frac ? 1 : (sps <= 4 ? 4 : (sps <= 8 ? 2 : 1)); }
+
+__global__ __launch_bounds__(1024) void seg_phase_k(const float2 *__restrict__ tiles, int rows,
+                                                    const int *__restrict__ lens, int S, int sps, int n_sym,
+                                                    double *__restrict__ mu0, const float2 *__restrict__ tile0, int frac)
+{
+    // one wave per (sampling phase, part) (sps <= 8), each adding its strobes in k order, 16 loads in flight;
+    // wave 0 then adds the parts and takes the first maximum over the phases, or the line's phase
+    __shared__ double e[16][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, tile = blockIdx.x, w = tile * 64 + lane;
     const int len = w < S ? lens[w] : 0;
     const int ns = n_sym < len / sps ? n_sym : len / sps;
     // (rows = rows between consecutive tiles' row 0; tile 0 may live elsewhere: SyncParams x_tile_rows / x_tile0)
     const float2 *base = (tile == 0 && tile0 ? tile0 : tiles + (ptrdiff_t)tile * rows * 64) + lane;
     if (sps <= 8) {
+        const int parts = seg_phase_parts(sps, frac), ph = wv / parts, part = wv - ph * parts;
+        const int plen = (ns + parts - 1) / parts;
+        const int k_lo = part * plen, k_hi = k_lo + plen < ns ? k_lo + plen : ns;
         double acc = 0.0;
-        for (int k0 = 0; k0 < ns; k0 += 8) {
-            float2 v[8];
+        for (int k0 = k_lo; k0 < k_hi; k0 += 16) {
+            float2 v[16];
 #pragma unroll
-            for (int kk = 0; kk < 8; kk++)
-                v[kk] = k0 + kk < ns ? base[(size_t)((k0 + kk) * sps + wv) * 64] : float2{0.f, 0.f};
+            for (int kk = 0; kk < 16; kk++)
+                v[kk] = k0 + kk < k_hi ? base[(size_t)((k0 + kk) * sps + ph) * 64] : float2{0.f, 0.f};
 #pragma unroll
-            for (int kk = 0; kk < 8; kk++)
-                if (k0 + kk < ns) acc += (double)v[kk].x * (double)v[kk].x + (double)v[kk].y * (double)v[kk].y;
+            for (int kk = 0; kk < 16; kk++)
+                if (k0 + kk < k_hi) acc += (double)v[kk].x * (double)v[kk].x + (double)v[kk].y * (double)v[kk].y;
         }
         e[wv][lane] = acc;
         __syncthreads();
         if (wv == 0 && w < S) {
-            double best = -1.0;
-            int arg = 0;
-            for (int p = 0; p < sps; p++)
-                if (e[p][lane] > best) { best = e[p][lane]; arg = p; }
-            mu0[w] = (double)arg;
+            double ep[8];
+            for (int p = 0; p < sps; p++) {
+                double t = e[p * parts][lane];
+                for (int q = 1; q < parts; q++) t += e[p * parts + q][lane];
+                ep[p] = t;
+            }
+            mu0[w] = seg_phase_pick(ep, 1, sps, frac);
         }
     } else if (wv == 0 && w < S) {
-        double best = -1.0;
+        // one lane per window, phase after phase (the sample grid: first maximum)
+        double best = -1.0, cs = 0.0, sn = 0.0;
         int arg = 0;
         for (int p = 0; p < sps; p++) {
             double acc = 0.0;
@@ -262,8 +319,11 @@ __global__ __launch_bounds__(512) void seg_phase_k(const float2 *__restrict__ ti
                 acc += (double)v.x * (double)v.x + (double)v.y * (double)v.y;
             }
             if (acc > best) { best = acc; arg = p; }
+            const double t = (double)p / (double)sps;
+            cs += acc * cospi(2.0 * t);
+            sn += acc * sinpi(2.0 * t);
         }
-        mu0[w] = (double)arg;
+        mu0[w] = frac ? seg_phase_tau(cs, sn, sps) : (double)arg;
     }
 }
 
@@ -466,10 +526,11 @@ hipError_t launch_seg_lead_copy(void *tiles, int rows, const int64_t *starts, in
 }
 
 hipError_t launch_seg_phase(const void *tiles, int rows, const int *lens, int S, int sps, int n_sym, double *mu0,
-                            hipStream_t s, int x_tile_rows, const void *x_tile0)
+                            hipStream_t s, int x_tile_rows, const void *x_tile0, int frac)
 {
-    hipLaunchKernelGGL(seg_phase_k, dim3((S + 63) / 64), dim3(sps <= 8 ? 64 * sps : 64), 0, s, (const float2 *)tiles,
-                       x_tile_rows ? x_tile_rows : rows, lens, S, sps, n_sym, mu0, (const float2 *)x_tile0);
+    hipLaunchKernelGGL(seg_phase_k, dim3((S + 63) / 64), dim3(sps <= 8 ? 64 * sps * seg_phase_parts(sps, frac) : 64), 0, s,
+                       (const float2 *)tiles,
+                       x_tile_rows ? x_tile_rows : rows, lens, S, sps, n_sym, mu0, (const float2 *)x_tile0, frac);
     return hipGetLastError();
 }
 

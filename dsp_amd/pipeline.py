@@ -172,8 +172,8 @@ class CapturePipeline:
     decisions (and mu / frequency per symbol) stay on the device until fetch()."""
 
     def __init__(self, ctx, n_samples, sps=4, span=10, rolloff=0.35, alpha=0.007, mu0=0.0, Bn=0.003,
-                 y=1.0, seg_len=None, warmup=4096, int16=True, matched_filter=True, want_mu=True,
-                 want_freq=False, acquire=True):
+                 y=1.0, seg_len=None, warmup=2048, int16=True, matched_filter=True, want_mu=True,
+                 want_freq=False, acquire=2):
         self.ctx, self.L = ctx, _lib.lib()
         self.n, self.sps = int(n_samples), int(sps)
         self.kind = DSP_I16 if int16 else DSP_C64
@@ -198,7 +198,7 @@ class CapturePipeline:
         if matched_filter:
             a.h = self.d_taps; a.n_taps = self.taps.size
         a.sps = self.sps; a.alpha = alpha; a.mu0 = mu0; a.Bn = Bn; a.y = y
-        a.seg_len = int(seg_len); a.warmup = int(warmup); a.acquire = int(bool(acquire))
+        a.seg_len = int(seg_len); a.warmup = int(warmup); a.acquire = int(acquire)
         a.dec = self.d_dec; a.mu = self.d_mu; a.freq = self.d_freq; a.capacity = self.cap
         a.n_symbols = C.addressof(self.total); a.seg_info = self.info.ctypes.data
         self._args = a

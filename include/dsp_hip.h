@@ -366,10 +366,16 @@ typedef struct dsp_capture_args {
     int32_t acquire;        /* 1: every window starts its timing loop at the sampling phase (0..sps-1)
                                whose strobes carry the most energy over its first DSP_ACQUIRE_SYMBOLS
                                symbols (a cold start half a symbol off can hang on the Gardner S-curve's
-                               unstable zero for longer than any warm-up); 0: every window starts at mu0 */
+                               unstable zero for longer than any warm-up); 2: at the fractional phase of
+                               the same energies' symbol-rate line over DSP_ACQUIRE_FRAC_SYMBOLS symbols,
+                               atan2(sum E_p sin(2 pi p / sps), sum E_p cos(2 pi p / sps)) sps / (2 pi) in
+                               [0, sps), rounded to 1/1024 sample -- some 0.01 sample rms from the lock
+                               point instead of up to half a sample, so a 2048-symbol warm-up leaves what
+                               a 4096-symbol one leaves after 1; 0: every window starts at mu0          */
     int32_t reserved;
 } dsp_capture_args;
 #define DSP_ACQUIRE_SYMBOLS 256
+#define DSP_ACQUIRE_FRAC_SYMBOLS 512
 /* The segment-parallel calls keep their large device work buffers (window tiles, per-window output
  * tiles) in the context between calls; dsp_trim releases them (dsp_destroy does too).  The host-pointer
  * entry points likewise keep their device blocks (<= 1 GiB per process) for the next call: dsp_trim returns

@@ -270,11 +270,59 @@ def acquire_phase(w, sps, n_sym=256):
     return float(arg)
 
 
+ACQ_FRAC_SYMBOLS = 512          # strobes per phase behind the fractional start (acquire = 2)
+ACQ_FRAC_STEPS = 1024           # ... which is rounded to 1/1024 sample
+
+
+def _cos_sin_turns(t):
+    """cos, sin of t turns, exact at the quarter turns (what cospi / sinpi give on the device)."""
+    t = t - np.floor(t)
+    for k, v in ((0.0, (1.0, 0.0)), (0.25, (0.0, 1.0)), (0.5, (-1.0, 0.0)), (0.75, (0.0, -1.0))):
+        if t == k:
+            return v
+    return float(np.cos(2.0 * np.pi * t)), float(np.sin(2.0 * np.pi * t))
+
+
+def acquire_phase_frac(w, sps, n_sym=ACQ_FRAC_SYMBOLS):
+    """Fractional initial timing phase of a window (dsp_capture_args.acquire = 2): the strobe energies
+    E_p of acquire_phase are samples of A + B cos(2 pi (t - tau) / sps) -- the symbol-rate line of
+    |x|^2 (Oerder-Meyr) -- so tau = atan2(sum E_p sin(2 pi p / sps), sum E_p cos(2 pi p / sps)) * sps
+    / (2 pi), taken into [0, sps) and rounded to 1 / 1024 sample (the rounding makes the start the
+    same number wherever atan2 and the trigonometric table differ in their last bits).  The strobes
+    of a phase are added in `parts` contiguous parts of ceil(ns / parts) (4 parts up to sps 4, 2 up
+    to 8, else 1; k order inside a part, then the parts first to last): the device gives each part
+    a wave."""
+    ns = min(n_sym, len(w) // sps)
+    re = w.real.astype(np.float64)
+    im = w.imag.astype(np.float64)
+    parts = 4 if sps <= 4 else (2 if sps <= 8 else 1)
+    plen = (ns + parts - 1) // parts
+    c_sum, s_sum = 0.0, 0.0
+    for p in range(sps):
+        i = np.arange(ns) * sps + p
+        en = (re[i] * re[i] + im[i] * im[i]).tolist()
+        acc = None
+        for q in range(parts):
+            t = 0.0
+            for v in en[q * plen:min(ns, (q + 1) * plen)]:          # float64 sums in k order
+                t += v
+            acc = t if acc is None else acc + t
+        c, s = _cos_sin_turns(p / sps)
+        c_sum += acc * c
+        s_sum += acc * s
+    tau = float(np.arctan2(s_sum, c_sum)) * sps / (2.0 * np.pi)
+    if tau < 0.0:
+        tau += sps
+    q = float(np.floor(tau * ACQ_FRAC_STEPS + 0.5)) / ACQ_FRAC_STEPS
+    return q - sps if q >= sps else q
+
+
 def sync_capture_segmented(x, sps=4, alpha=0.007, mu0=0.0, Bn=0.003, y=1.0, seg_len=65536, warmup=2048,
-                           vote=None, scale=1.0, acquire=True):
+                           vote=None, scale=1.0, acquire=2):
     """x: the whole capture, complex64, already matched-filtered; scale: factor applied to the
     samples in float64 (1/std of the whole filtered stream when the device filters); acquire: start
-    every window at acquire_phase(window) instead of mu0."""
+    every window at acquire_phase_frac(window) (2, the default), at acquire_phase(window) (1 / True:
+    the sample grid) or at mu0 (0 / False)."""
     x = np.ascontiguousarray(x, dtype=np.complex64)
     n = x.size
     S = (n + seg_len - 1) // seg_len
@@ -284,7 +332,8 @@ def sync_capture_segmented(x, sps=4, alpha=0.007, mu0=0.0, Bn=0.003, y=1.0, seg_
     for s in range(S):
         st = max(0, s * seg_len - lead)
         en = n if s == S - 1 else min(n, (s + 1) * seg_len + tail)
-        m0 = acquire_phase(x[st:en], sps) if acquire else mu0
+        acq = int(acquire)
+        m0 = acquire_phase_frac(x[st:en], sps) if acq == 2 else (acquire_phase(x[st:en], sps) if acq else mu0)
         o = sync_chain_c64(x[st:en], sps=sps, alpha=alpha, mu0=m0, Bn=Bn, y=y, scale=scale)
         pos = _positions(float(st), o["mu"], o["n"], sps)
         wins.append((o, pos))

@@ -31,12 +31,15 @@ def _best_alignment(dec, centre, span=24):
     return best
 
 
-# (65536, 2048) is SURVEY.md 8(d)'s config 5 as written; None = the automatic segment length
-@pytest.mark.parametrize("seg_len,warmup", [(32768, 4096), (65536, 4096), (65536, 2048), (None, 2048)])
-def test_capture_2p30(ctx, seg_len, warmup):
+# (65536, 2048) is SURVEY.md 8(d)'s config 5 as written; None = the automatic segment length; acquire 1 = windows
+# started on the sample grid (round 2's definition), 2 = at the fractional phase (the default; bench.py's line
+# is (None, 2048, 2))
+@pytest.mark.parametrize("seg_len,warmup,acquire", [(32768, 4096, 1), (65536, 4096, 2), (65536, 2048, 2), (None, 2048, 2),
+                                                    (None, 1536, 2)])
+def test_capture_2p30(ctx, seg_len, warmup, acquire):
     from dsp_amd.pipeline import CapturePipeline
     n, sps, tau0, drift = 1 << 30, 4, 0.3, 2.0e-8
-    pipe = CapturePipeline(ctx, n, sps, seg_len=seg_len, warmup=warmup)
+    pipe = CapturePipeline(ctx, n, sps, seg_len=seg_len, warmup=warmup, acquire=acquire)
     try:
         pipe.generate(SEED, tau0=tau0, drift=drift)
         nsym = pipe.run()

@@ -220,7 +220,7 @@ def test_fuzz_segmented(ctx, oracle, trial):
     nsym = int(rng.choice([900, 3000, 7001]))
     seg_len = int(rng.choice([256, 1024, 4096, 65536])) * sps
     warm = int(rng.choice([0, 64, 300, 1000]))
-    acquire = bool(rng.integers(0, 2))
+    acquire = int(rng.integers(0, 3))
     h = dsp_amd.rrc_filter(sps, 10, 0.35)
     q = rng.integers(0, 4, nsym)
     sym = ((1 - 2 * (q & 1)) + 1j * (1 - 2 * (q >> 1))) / np.sqrt(2)
@@ -256,7 +256,7 @@ def test_fuzz_capture_with_matched_filter(ctx, oracle, trial):
     warm = int(rng.choice([0, 64, seg_len // sps // 2, seg_len // sps]))
     i16 = bool(rng.integers(0, 2))
     trim = int(rng.integers(0, seg_len // 4)) * 4 if rng.integers(0, 2) else 0
-    acquire = bool(rng.integers(0, 2))
+    acquire = int(rng.integers(0, 3))
     n = nseg * seg_len - trim
     h = dsp_amd.rrc_filter(sps, 10, 0.35)
     nsym = n // sps + 8

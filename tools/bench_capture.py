@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Config 5 of BASELINE.json: one continuous int16 IQ capture, segment-parallel receiver.
 
-    python tools/bench_capture.py [log2_samples=28] [seg_len=auto] [warmup=4096] [trim=0]
+    python tools/bench_capture.py [log2_samples=28] [seg_len=auto] [warmup=2048] [trim=0]
 
 (trim: the capture is 2^log2_samples - trim samples long, for sizes that are not whole segments)
 
@@ -50,7 +50,7 @@ def check_decisions(pipe, n_sym, tau0, drift, sps, lo, count):
 def main():
     lg = int(sys.argv[1]) if len(sys.argv) > 1 else 28
     seg_len = int(sys.argv[2]) if len(sys.argv) > 2 and int(sys.argv[2]) > 0 else None
-    warmup = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
+    warmup = int(sys.argv[3]) if len(sys.argv) > 3 else 2048
     trim = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     n, sps = (1 << lg) - trim, 4
     tau0, drift = 0.3, 2.0e-8
