@@ -667,9 +667,8 @@ static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, c
     const int elem = a->dtype == DSP_C128 ? 16 : 8;
     const int ntiles = (P.B + 63) / 64;
     // two waves per tile: both loops run, and the interpolator is the reference's linear one or a
-    // Lagrange order the two-wave kernel is built for (half_len 1, 2, 3, 4, 6, 8; sync_kernels.hip parts 1-4)
-    const bool lagr_built = P.half_len == 1 || P.half_len == 2 || P.half_len == 3 || P.half_len == 4 ||
-                            P.half_len == 6 || P.half_len == 8;
+    // Lagrange order (half_len 1 ... 8: sync_kernels.hip parts 1-6)
+    const bool lagr_built = P.half_len >= 1 && P.half_len <= 8;
     const bool can_split = fll && a->variant != 2 && (P.half_len == 0 || lagr_built);
     const int n_store_t = count_nonnull({P.rec, P.terr, P.mu, P.pos});
     const int n_store_f = count_nonnull({P.sig, P.freq, P.ef, P.dec});

@@ -26,7 +26,7 @@
 #include "sync_lane.h"
 
 // This file is compiled five times (Makefile): part 0 holds every kernel with the reference's linear
-// interpolator, the one-wave kernels and the launch logic; parts 1-4 (-DDSP_SYNC_PART=n) only the
+// interpolator, the one-wave kernels and the launch logic; parts 1-6 (-DDSP_SYNC_PART=n) only the
 // two-wave kernel with the Lagrange interpolator inside the timing loop (gardner2 / gardner_ted, half_len
 // 1, 2, 4 / 3, 6, 8), so that the sets of instantiations build side by side.
 #ifndef DSP_SYNC_PART
@@ -1470,8 +1470,8 @@ __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void 
 #if DSP_SYNC_PART >= 1
 // The two-wave kernel with the Lagrange interpolator inside the timing loop, one translation unit per
 // (variant, set of orders) so that they build side by side:
-//   part 1  gardner2, half_len 1, 2, 4      part 2  gardner2, half_len 3, 6, 8
-//   part 3  gardner_ted, half_len 1, 2, 4   part 4  gardner_ted, half_len 3, 6, 8
+//   part 1  gardner2, half_len 1, 2, 4      part 2  gardner2, half_len 3, 6, 8      part 5  gardner2, half_len 5, 7
+//   part 3  gardner_ted, half_len 1, 2, 4   part 4  gardner_ted, half_len 3, 6, 8   part 6  gardner_ted, half_len 5, 7
 // gardner2: straight-line steady iteration (g2_steady_lagr), two waves per tile or four (two of them
 // chosen by the CU ticket, see above).  gardner_ted: the per-lane iteration (ted_iter + lagrange_at) on
 // the timing wave, the FLL on its own wave.
@@ -1479,15 +1479,19 @@ __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void 
 #define DSP_LAGR_HA 1
 #define DSP_LAGR_HB 2
 #define DSP_LAGR_HC 4
-#else
+#elif DSP_SYNC_PART == 2 || DSP_SYNC_PART == 4
 #define DSP_LAGR_HA 3
 #define DSP_LAGR_HB 6
 #define DSP_LAGR_HC 8
+#else
+#define DSP_LAGR_HA 5
+#define DSP_LAGR_HB 7
+#define DSP_LAGR_HC 0
 #endif
 template <typename IN>
 static hipError_t launch_split_lagr_t(const SyncParams &P, size_t lds, hipStream_t s)
 {
-    constexpr int VAR = DSP_SYNC_PART <= 2 ? DSP_VARIANT_GARDNER2 : DSP_VARIANT_TED;
+    constexpr int VAR = (DSP_SYNC_PART <= 2 || DSP_SYNC_PART == 5) ? DSP_VARIANT_GARDNER2 : DSP_VARIANT_TED;
     const int ntiles = (P.B + 63) / 64;
     const bool four = VAR == DSP_VARIANT_GARDNER2 && P.spare_wave == 2 && P.cu_tickets;
     void (*k)(SyncParams) = nullptr;
@@ -1502,7 +1506,9 @@ static hipError_t launch_split_lagr_t(const SyncParams &P, size_t lds, hipStream
     switch (P.half_len) {
         case DSP_LAGR_HA: pick(std::integral_constant<int, DSP_LAGR_HA>{}); break;
         case DSP_LAGR_HB: pick(std::integral_constant<int, DSP_LAGR_HB>{}); break;
+#if DSP_LAGR_HC
         case DSP_LAGR_HC: pick(std::integral_constant<int, DSP_LAGR_HC>{}); break;
+#endif
         default: return hipErrorInvalidValue;
     }
     if (lds > 64 * 1024) {
@@ -1528,6 +1534,8 @@ hipError_t launch_sync_split_lagr_part1(const SyncParams &P, bool c128, size_t l
 hipError_t launch_sync_split_lagr_part2(const SyncParams &P, bool c128, size_t lds, hipStream_t s);
 hipError_t launch_sync_split_lagr_part3(const SyncParams &P, bool c128, size_t lds, hipStream_t s);
 hipError_t launch_sync_split_lagr_part4(const SyncParams &P, bool c128, size_t lds, hipStream_t s);
+hipError_t launch_sync_split_lagr_part5(const SyncParams &P, bool c128, size_t lds, hipStream_t s);
+hipError_t launch_sync_split_lagr_part6(const SyncParams &P, bool c128, size_t lds, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // Ring schedule.  Iteration `it` of the timing loop touches rows
@@ -1575,11 +1583,13 @@ template <typename IN>
 static hipError_t launch_in(const SyncParams &P, int variant, bool fll, size_t lds, hipStream_t s)
 {
     if (P.TQ > 0 && P.half_len > 0) { // ... with the Lagrange interpolator: the other translation units
-        const bool set2 = P.half_len == 3 || P.half_len == 6 || P.half_len == 8;
+        const bool set2 = P.half_len == 3 || P.half_len == 6 || P.half_len == 8, set3 = P.half_len == 5 || P.half_len == 7;
         if (variant == DSP_VARIANT_GARDNER2)
-            return set2 ? launch_sync_split_lagr_part2(P, sizeof(IN) == 16, lds, s)
+            return set3 ? launch_sync_split_lagr_part5(P, sizeof(IN) == 16, lds, s)
+                 : set2 ? launch_sync_split_lagr_part2(P, sizeof(IN) == 16, lds, s)
                         : launch_sync_split_lagr_part1(P, sizeof(IN) == 16, lds, s);
-        return set2 ? launch_sync_split_lagr_part4(P, sizeof(IN) == 16, lds, s)
+        return set3 ? launch_sync_split_lagr_part6(P, sizeof(IN) == 16, lds, s)
+             : set2 ? launch_sync_split_lagr_part4(P, sizeof(IN) == 16, lds, s)
                     : launch_sync_split_lagr_part3(P, sizeof(IN) == 16, lds, s);
     }
     if (P.TQ > 0) {        // two waves per tile (timing wave + FLL wave)

@@ -351,7 +351,7 @@ def test_fuzz_lagrange_and_continuation(ctx, oracle, trial):
     from test_gpu_lagrange import gardner2_lagrange_restated
     rng = np.random.default_rng(13000 + trial)
     sps = int(rng.choice([2, 4]))
-    half = int(rng.choice([1, 2, 4]))
+    half = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8]))
     B, N = int(rng.choice([14, 66])), 320
     X = np.stack([_burst(rng, N, sps, 1) for _ in range(B)])
     lens = rng.integers(6 * sps, N + 1, B).astype(np.int32)

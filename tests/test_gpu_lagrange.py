@@ -95,9 +95,10 @@ def test_gardner_with_lagrange_interpolator(oracle, ctx):
 
 
 @pytest.mark.parametrize("halves,picks", [((1, 2, 4), list(range(0, 70, 9)) + [1, 2, 3, 63, 64, 69]),
-                                          ((3, 6, 8), [0, 1, 2, 3, 36, 63, 64, 69])])
+                                          ((3, 6, 8), [0, 1, 2, 3, 36, 63, 64, 69]),
+                                          ((5, 7), [0, 2, 3, 37, 63, 64, 69])])
 def test_lagrange_two_wave_kernel_full_tiles_ragged(oracle, ctx, halves, picks):
-    """interp_half_len 1, 2, 4 (round 2) and 3, 6, 8 (round 3: 6 is the order of the reference's own worked
+    """interp_half_len 1, 2, 4 (round 2) and 3, 5, 6, 7, 8 (round 3: 6 is the order of the reference's own worked
     Lagrange scenario, hw1/test_lagrange_resampling.py:157) through the fused chain (both loops -> the two-wave kernel, whose timing
     wave interpolates out of the LDS ring with product-form Lagrange basis values): full tiles of
     bursts with ragged lengths, every burst against the restated loop to 1e-12 -- the per-lane code
@@ -171,7 +172,7 @@ def test_gardner_ted_with_lagrange_on_the_two_wave_kernel(oracle, ctx):
     Y = Y * (1.0 + 0.02 * np.arange(66))[:, None]
     lens = np.full(66, 1500, np.int32)
     lens[:3] = [1500, 1203, 900]
-    for half in (1, 2, 3, 4, 6, 8):
+    for half in (1, 2, 3, 4, 5, 6, 7, 8):
         r = dsp_amd.sync_chain_batch(Y, 4, 0.002, 0.0, 0.03, 1, variant=1, interp_half_len=half,
                                      lens=lens, outputs=("rec", "err", "mu", "dec", "freq"), ctx=ctx)
         ctx.set_option("split", 0)
