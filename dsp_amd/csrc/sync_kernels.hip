@@ -43,22 +43,34 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 typedef double d2v __attribute__((ext_vector_type(2)));
 
 // ---- asm VMEM helpers (exactly one vector-memory instruction each) ---------
+// Cache-policy bits for A/B builds: -DDSP_DMA_NT appends `nt` to every LDS-DMA load, -DDSP_ST_NT to the
+// hot paths' stores through wave-uniform bases (the product builds neither: no gain measured)
+#ifdef DSP_DMA_NT
+#define DSP_DMA_MOD " nt"
+#else
+#define DSP_DMA_MOD ""
+#endif
+#ifdef DSP_ST_NT
+#define DSP_ST_MOD " nt"
+#else
+#define DSP_ST_MOD ""
+#endif
 __device__ __forceinline__ void lds_dma_16B(const void *g, unsigned lds_off)
 {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" DSP_DMA_MOD
                  :: "v"(g), "s"(lds_off) : "memory", "m0");
 }
 __device__ __forceinline__ void lds_dma_pair(const void *g, unsigned lds_off)
 {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024"
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" DSP_DMA_MOD "\n\tglobal_load_lds_dwordx4 %0, off offset:1024" DSP_DMA_MOD
                  :: "v"(g), "s"(lds_off) : "memory", "m0");
 }
 // n (1..4) consecutive 1 KiB pieces with one M0 / one address: the instruction offset moves
 // the global and the LDS address together
 __device__ __forceinline__ void lds_dma_group(const void *g, unsigned lds_off, int n)
 {
-#define DMA0 "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-#define DMAN(o) "\n\tglobal_load_lds_dwordx4 %0, off offset:" #o
+#define DMA0 "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" DSP_DMA_MOD
+#define DMAN(o) "\n\tglobal_load_lds_dwordx4 %0, off offset:" #o DSP_DMA_MOD
     switch (n) {
         case 1: asm volatile(DMA0 :: "v"(g), "s"(lds_off) : "memory", "m0"); break;
         case 2: asm volatile(DMA0 DMAN(1024) :: "v"(g), "s"(lds_off) : "memory", "m0"); break;
@@ -123,13 +135,13 @@ __device__ __forceinline__ void st_cplx(d2v *p, double re, double im, bool keep 
 #if DSP_SST_GUARD == 1
 #define DSP_SST(OPC, TAIL)                                                                          \
     unsigned long long tb;                                                                          \
-    asm volatile("s_mov_b64 %0, %3\n\t" OPC " %1, %2, %0" TAIL : "=&s"(tb) : "v"(voff), "v"(v), "s"(base) : "memory")
+    asm volatile("s_mov_b64 %0, %3\n\t" OPC " %1, %2, %0" DSP_ST_MOD TAIL : "=&s"(tb) : "v"(voff), "v"(v), "s"(base) : "memory")
 #elif DSP_SST_GUARD == 2
 #define DSP_SST(OPC, TAIL)                                                                          \
-    asm volatile("s_nop 4\n\t" OPC " %0, %1, %2" TAIL :: "v"(voff), "v"(v), "s"(base) : "memory")
+    asm volatile("s_nop 4\n\t" OPC " %0, %1, %2" DSP_ST_MOD TAIL :: "v"(voff), "v"(v), "s"(base) : "memory")
 #else   // 0: no guard -- round 2's text, for A/B timing only; the lint decides whether such a build may exist
 #define DSP_SST(OPC, TAIL)                                                                          \
-    asm volatile(OPC " %0, %1, %2" TAIL :: "v"(voff), "v"(v), "s"(base) : "memory")
+    asm volatile(OPC " %0, %1, %2" DSP_ST_MOD TAIL :: "v"(voff), "v"(v), "s"(base) : "memory")
 #endif
 __device__ __forceinline__ void sst(const void *base, unsigned voff, float v) { DSP_SST("global_store_dword", ""); }
 __device__ __forceinline__ void sst(const void *base, unsigned voff, double v) { DSP_SST("global_store_dwordx2", ""); }
@@ -149,45 +161,45 @@ template <typename OC> struct GroupStore;
         static __device__ __forceinline__ void c_s_s(unsigned oc, OC_T c, const void *bc, unsigned os, OS_T a,   \
                                                      const void *ba, OS_T b, const void *bb)                    \
         {                                                                                                         \
-            asm volatile("s_nop 4\n\t" OCOP " %0, %1, %2\n\t" OSOP " %3, %4, %5\n\t" OSOP " %3, %6, %7" PAD        \
+            asm volatile("s_nop 4\n\t" OCOP " %0, %1, %2" DSP_ST_MOD "\n\t" OSOP " %3, %4, %5" DSP_ST_MOD "\n\t" OSOP " %3, %6, %7" DSP_ST_MOD PAD        \
                          :: "v"(oc), "v"(c), "s"(bc), "v"(os), "v"(a), "s"(ba), "v"(b), "s"(bb) : "memory");      \
         }                                                                                                         \
         static __device__ __forceinline__ void c_s_s_s(unsigned oc, OC_T c, const void *bc, unsigned os, OS_T a, \
                                                        const void *ba, OS_T b, const void *bb, OS_T d,          \
                                                        const void *bd)                                           \
         {                                                                                                         \
-            asm volatile("s_nop 4\n\t" OCOP " %0, %1, %2\n\t" OSOP " %3, %4, %5\n\t" OSOP " %3, %6, %7\n\t"        \
-                         OSOP " %3, %8, %9" PAD                                                                    \
+            asm volatile("s_nop 4\n\t" OCOP " %0, %1, %2" DSP_ST_MOD "\n\t" OSOP " %3, %4, %5" DSP_ST_MOD "\n\t" OSOP " %3, %6, %7" DSP_ST_MOD "\n\t"        \
+                         OSOP " %3, %8, %9" DSP_ST_MOD PAD                                                                    \
                          :: "v"(oc), "v"(c), "s"(bc), "v"(os), "v"(a), "s"(ba), "v"(b), "s"(bb), "v"(d), "s"(bd)  \
                          : "memory");                                                                             \
         }                                                                                                         \
         static __device__ __forceinline__ void s_s(unsigned os, OS_T a, const void *ba, OS_T b, const void *bb)  \
         {                                                                                                         \
-            asm volatile("s_nop 4\n\t" OSOP " %0, %1, %2\n\t" OSOP " %0, %3, %4"                                   \
+            asm volatile("s_nop 4\n\t" OSOP " %0, %1, %2" DSP_ST_MOD "\n\t" OSOP " %0, %3, %4" DSP_ST_MOD                                   \
                          :: "v"(os), "v"(a), "s"(ba), "v"(b), "s"(bb) : "memory");                                \
         }                                                                                                         \
         static __device__ __forceinline__ void s(unsigned os, OS_T a, const void *ba)                            \
         {                                                                                                         \
-            asm volatile("s_nop 4\n\t" OSOP " %0, %1, %2" :: "v"(os), "v"(a), "s"(ba) : "memory");                \
+            asm volatile("s_nop 4\n\t" OSOP " %0, %1, %2" DSP_ST_MOD :: "v"(os), "v"(a), "s"(ba) : "memory");                \
         }                                                                                                         \
         static __device__ __forceinline__ void c_s_s_b(unsigned oc, OC_T c, const void *bc, unsigned os, OS_T a, \
                                                        const void *ba, OS_T b, const void *bb, unsigned ob,     \
                                                        unsigned q, const void *bq)                               \
         {                                                                                                         \
-            asm volatile("s_nop 4\n\t" OCOP " %0, %1, %2\n\t" OSOP " %3, %4, %5\n\t" OSOP " %3, %6, %7\n\t"        \
-                         "global_store_byte %8, %9, %10" PAD                                                       \
+            asm volatile("s_nop 4\n\t" OCOP " %0, %1, %2" DSP_ST_MOD "\n\t" OSOP " %3, %4, %5" DSP_ST_MOD "\n\t" OSOP " %3, %6, %7" DSP_ST_MOD "\n\t"        \
+                         "global_store_byte %8, %9, %10" DSP_ST_MOD PAD                                                       \
                          :: "v"(oc), "v"(c), "s"(bc), "v"(os), "v"(a), "s"(ba), "v"(b), "s"(bb), "v"(ob), "v"(q), \
                             "s"(bq) : "memory");                                                                  \
         }                                                                                                         \
         static __device__ __forceinline__ void s_b(unsigned os, OS_T a, const void *ba, unsigned ob, unsigned q, \
                                                    const void *bq)                                               \
         {                                                                                                         \
-            asm volatile("s_nop 4\n\t" OSOP " %0, %1, %2\n\tglobal_store_byte %3, %4, %5"                         \
+            asm volatile("s_nop 4\n\t" OSOP " %0, %1, %2" DSP_ST_MOD "\n\tglobal_store_byte %3, %4, %5" DSP_ST_MOD                         \
                          :: "v"(os), "v"(a), "s"(ba), "v"(ob), "v"(q), "s"(bq) : "memory");                       \
         }                                                                                                         \
         static __device__ __forceinline__ void b(unsigned ob, unsigned q, const void *bq)                        \
         {                                                                                                         \
-            asm volatile("s_nop 4\n\tglobal_store_byte %0, %1, %2" :: "v"(ob), "v"(q), "s"(bq) : "memory");       \
+            asm volatile("s_nop 4\n\tglobal_store_byte %0, %1, %2" DSP_ST_MOD :: "v"(ob), "v"(q), "s"(bq) : "memory");       \
         }                                                                                                         \
     }
 DSP_GS_IMPL(f2v, float, "global_store_dwordx2", "global_store_dword", "");
@@ -1045,7 +1057,12 @@ __device__ __forceinline__ unsigned wave_slot()
 #ifndef DSP_SPLIT_MIN_WAVES
 #define DSP_SPLIT_MIN_WAVES 1
 #endif
-template <typename IN, int VARIANT, bool SC, int NWV, int H = 0>
+#ifdef DSP_NOSPEC            // A/B builds: every instantiation without the speculative segments
+#define DSP_SPECT_DEFAULT false
+#else
+#define DSP_SPECT_DEFAULT true
+#endif
+template <typename IN, int VARIANT, bool SC, int NWV, int H = 0, bool SPECT = DSP_SPECT_DEFAULT>
 __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void sync_split_kernel(SyncParams P)
 {
     typedef typename InT<IN>::OS OS;
@@ -1196,7 +1213,7 @@ __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void 
         int n_steady = 0;
         // speculative segments (g2_spec_segment): gardner2 with the linear interpolator, ring in use and
         // starting on a multiple of its size
-        constexpr bool SPEC = (VARIANT == DSP_VARIANT_GARDNER2 && H == 0);
+        constexpr bool SPEC = (SPECT && VARIANT == DSP_VARIANT_GARDNER2 && H == 0);
         const int tmask = (o_rec ? 1 : 0) | (o_terr ? 2 : 0) | (o_mu ? 4 : 0) | (o_pos ? 8 : 0);
         const bool spec_cfg = SPEC && ring && P.spec != 0 &&
                               (tl.lds_base & ((unsigned)tl.R * 64u * (unsigned)sizeof(IN) - 1u)) == 0u;
@@ -1377,7 +1394,7 @@ __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void 
         int it = 0;
         prio_n = prio_n ? (prio_n * T / TQ > 0 ? prio_n * T / TQ : 1) : 0;     // same period in queue blocks
         prio_c = 1;
-        constexpr bool SPEC = (VARIANT == DSP_VARIANT_GARDNER2 && H == 0);
+        constexpr bool SPEC = (SPECT && VARIANT == DSP_VARIANT_GARDNER2 && H == 0);
         const int fmask = (o_sig ? 1 : 0) | (o_freq ? 2 : 0) | (o_ef ? 4 : 0) | (o_dec ? 8 : 0);
         const size_t tile_el = (size_t)tile * out_rows * 64;
         const SpecBasesF fbases = {o_sig ? (const unsigned char *)(o_sig + tile_el) : nullptr,

@@ -187,7 +187,7 @@ int main(int argc, char **argv)
         }
         CHECK(hipFree(y));
     }
-    for (int var : {0}) { const int spin = 0;
+    for (int var : {0, 2, 3}) { const int spin = 0;   // 2: nt loads, 3: nt loads + nt stores
         for (int mode : {1, 6, 7}) {
             for (int r = 0; r < 2; r++) {
                 hipLaunchKernelGGL(k, dim3(ntiles), dim3(128), lds, 0, x, o[0], o[1], o[2], o[3], o[4], o[5], o[6],
