@@ -64,3 +64,49 @@ def test_capture_2p30(ctx, seg_len, warmup, acquire):
         assert np.array_equal(pipe.fetch("dec", nsym // 2, nsym // 2 + (1 << 20)), d0)
     finally:
         pipe.close()
+
+
+@pytest.mark.parametrize("warmup", [2048])
+def test_capture_2p30_windows_against_the_oracle(ctx, oracle, warmup):
+    """Oracle parity INSIDE the full-size capture.  A complex64 capture of 2^30 samples that needs no filter
+    (so a window depends on nothing but its own samples: no whole-stream peak or std) goes through the
+    segment-parallel receiver; runs of 192 consecutive segments -- the stream's first, a run from its middle
+    and its last -- are then handed to the CPU oracle's segmented definition as streams of their own.
+    Away from an excerpt's artificial ends (two windows) its windows see the same samples, warm-up and
+    neighbours as in the capture, so their shares (first / end row, rows produced), their decisions (up to
+    the ONE rotation the two chains of votes differ by) and their mu values (float32) must be the device's,
+    bit for bit; at the capture's true start and end the excerpt's end windows are compared too."""
+    from dsp_amd.pipeline import CapturePipeline
+    n, sps, K = 1 << 30, 4, 192
+    pipe = CapturePipeline(ctx, n, sps, warmup=warmup, int16=False, matched_filter=False)
+    try:
+        pipe.generate(SEED, tau0=0.3, drift=2.0e-8)
+        nsym = pipe.run()
+        info = pipe.info.astype(np.int64)
+        L, S = pipe.seg_len, pipe.S
+        assert S * L == n and S > 3 * K
+        share = info[:, 1] - info[:, 0]
+        off = np.concatenate(([0], np.cumsum(share)))           # where window w's share starts in the stitched stream
+        assert off[-1] == nsym
+        for w0, j_lo, j_hi in ((0, 0, K - 2), (S // 2 - 7, 2, K - 2), (S - K, 2, K)):
+            ex = np.empty(K * L, np.complex64)
+            ctx.d2h(ex, pipe.d_x + w0 * L * 8)
+            ref = oracle.sync_capture_segmented(ex, sps, 0.007, 0.0, 0.003, 1.0, seg_len=L, warmup=warmup, acquire=2)
+            rinfo = ref["seg_info"].astype(np.int64)
+            roff = np.concatenate(([0], np.cumsum(rinfo[:, 1] - rinfo[:, 0])))
+            turns = set()
+            for j in range(j_lo, j_hi):
+                w = w0 + j
+                assert tuple(info[w, [0, 1, 3]]) == tuple(rinfo[j, [0, 1, 3]]), (w0, j, info[w], rinfo[j])
+                turn = int(info[w, 2] - rinfo[j, 2]) & 3
+                turns.add(turn)
+                r = ref["dec"][roff[j]:roff[j + 1]].copy()
+                for _ in range(turn):
+                    r = TURN[r]
+                assert np.array_equal(pipe.fetch("dec", int(off[w]), int(off[w + 1])), r), (w0, j)
+                assert np.array_equal(pipe.fetch("mu", int(off[w]), int(off[w + 1])), ref["mu"][roff[j]:roff[j + 1]]), (w0, j)
+            assert len(turns) == 1, (w0, turns)
+            if w0 == 0:
+                assert turns == {0}                              # the same chain of votes from the same first window
+    finally:
+        pipe.close()

@@ -71,6 +71,54 @@ def test_pipeline_fullsize(ctx, oracle, B, split):
         ctx.set_option("split", -1)
 
 
+def test_every_burst_of_the_bench_batch_against_the_oracle(ctx, oracle):
+    """BASELINE.json config 4 on one GPU, the bench line's workload: ALL 65 536 bursts (not a sample of
+    tiles) through the fused kernel and through the CPU oracle on the same matched-filtered complex64
+    input and the same 1/std -- decisions, symbol counts, the timing trajectory and the recovered
+    samples bit-exact (after the device's float32 rounding of the outputs), the frequency trajectory
+    <= 1e-9.  The oracle runs one burst per call on a pool of host threads (ctypes releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    import os
+    from dsp_amd.pipeline import BurstPipeline
+    B, step = 65536, 4096
+    pipe = BurstPipeline(ctx, B, 2048, 4)
+    pipe.generate(SEED, b0=0)
+    pipe.matched_filter(free_raw=True)
+    pipe.run()
+    n_out = pipe.n_out()
+    try:
+        workers = min(16, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        workers = min(16, os.cpu_count() or 1)
+    bad = []
+    worst_f = 0.0
+
+    with ThreadPoolExecutor(workers) as ex:
+        for lo in range(0, B, step):
+            X = pipe.fetch_input(lo, lo + step)
+            inv = pipe.fetch_inv_std(lo, lo + step)
+            dec = pipe.fetch("dec", lo, lo + step)
+            mu = pipe.fetch("mu", lo, lo + step)
+            rec = pipe.fetch("rec", lo, lo + step)
+            freq = pipe.fetch("freq", lo, lo + step)
+
+            def check(b):
+                o = oracle.sync_chain_c64(X[b], scale=inv[b])
+                n = o["n"]
+                ok = (n == n_out[lo + b] and np.array_equal(dec[b, :n], o["dec"])
+                      and np.array_equal(mu[b, :n - 1], o["mu"].astype(np.float32))
+                      and np.array_equal(rec[b, :n], o["rec"].astype(np.complex64)))
+                return ok, float(np.max(np.abs(freq[b, :n] - o["freq"])))
+
+            for b, (ok, df) in enumerate(ex.map(check, range(step))):
+                worst_f = max(worst_f, df)
+                if not ok:
+                    bad.append(lo + b)
+    pipe.close()
+    assert not bad, (len(bad), bad[:8])
+    assert worst_f < 1e-9, worst_f
+
+
 def test_device_generator_statistics(ctx):
     """The device generator follows the 8(d) recipe: unit symbol energy, Es/N0 = 20 dB, CFO and
     delay inside their ranges, reproducible from (seed, burst)."""
