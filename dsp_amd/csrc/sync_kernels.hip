@@ -209,12 +209,13 @@ DSP_GS_IMPL(d2v, double, "global_store_dwordx4", "global_store_dwordx2", DSP_WID
 template <typename T>
 __device__ __forceinline__ T lds_ld(unsigned byte_addr)
 {
-    return *(const __attribute__((address_space(3))) T *)byte_addr;
+    // (through size_t: the host pass of the compiler takes every pointer for 64 bits wide and warns otherwise)
+    return *(const __attribute__((address_space(3))) T *)(size_t)byte_addr;
 }
 template <typename T>
 __device__ __forceinline__ void lds_st(unsigned byte_addr, T v)
 {
-    *(__attribute__((address_space(3))) T *)byte_addr = v;
+    *(__attribute__((address_space(3))) T *)(size_t)byte_addr = v;
 }
 
 // s_waitcnt takes its count as an immediate; the count here is a per-launch constant (stores issued per
