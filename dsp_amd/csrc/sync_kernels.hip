@@ -536,7 +536,7 @@ __device__ __forceinline__ bool g2_steady(const Tile<IN> &tl, dspm::GState &gs, 
 // vote (v_cmp -> s_cmp -> s_cbranch) stalls it for ~58: g2_steady above pays two votes per symbol and
 // its branches cut the symbol into basic blocks the scheduler cannot overlap.  Here nothing inside the
 // segment depends on a vote.  Every lane assumes what is true of a locked loop -- mu inside
-// [-sps, sps), the three instants in one binade (then idx_mid = idx_early + sps/2 and idx_late =
+// [-sps, sps), the three instants in one binade (then idx_mid = idx_early + (sps - sps // 2) and idx_late =
 // idx_early + sps hold EXACTLY, so one truncation and one fraction serve all three), the rows inside
 // the ring window, |alpha * e| < 1 (then the output instant lies within one sample of the late one) --
 // and records the evidence in four accumulators.  One vote at the end of the segment; if any lane's
@@ -590,7 +590,10 @@ __device__ __forceinline__ bool g2_spec_segment(const Tile<IN> &tl, dspm::GState
     const double alpha = tc.alpha, spsd = tc.spsd, scale = tl.scale;
     const int win_lo = tl.win_lo;
     const int wlim = tl.win_hi - win_lo - (tc.sps + 3);  // rows r_a .. r_a + sps + 2 inside [win_lo, win_hi)
-    const unsigned midb = (unsigned)(tc.sps / 2) * ROWB, lateb = (unsigned)tc.sps * ROWB;   // :74 integer half
+    // idx_mid = k - sps // 2 + mu (:74, integer half) lies sps - sps // 2 rows behind idx_early = k - sps + mu:
+    // 2 of 4, but 2 of 3 and 3 of 5 (sps / 2 rows, as this line read until the round-3 soak run, is right for
+    // even sps only: tests/test_gpu_sync.py::test_spec_segments_odd_sps)
+    const unsigned midb = (unsigned)(tc.sps - tc.sps / 2) * ROWB, lateb = (unsigned)tc.sps * ROWB;
     double mu = gs.mu;
     double kd = (double)gs.k, kd4 = kd - spsd;
     unsigned acc_x = 0u, acc_w = 0u, acc_mu = 0u, acc_e = 0u;

@@ -237,3 +237,39 @@ def test_fll_batch_state_continuation(ctx, oracle):
         o = oracle.fll_func(rec[i], 0.03, 1)
         assert np.max(np.abs(full[2][i] - o[2])) < FREQ_TOL
         assert np.array_equal(full[4][i], oracle.quadrants(o[0]))
+
+
+@pytest.mark.parametrize("sps", [2, 3, 5, 6, 7, 8])
+@pytest.mark.parametrize("c64", [True, False])
+def test_spec_segments_odd_sps(ctx, oracle, sps, c64):
+    """Full tiles of equally long bursts at samples-per-symbol other than 4, so that the steady path and its
+    speculative segments run (ragged tiles never get there): gardner2.py's idx_mid = k - sps // 2 + mu lies
+    sps - sps // 2 rows behind idx_early, which is sps // 2 for even sps only.  (The round-3 soak run,
+    DSP_FUZZ_SCALE=20, found the segment reading the mid instant one row early at sps 3: its trial 155 was the
+    first of the sweep with an odd sps AND a tile that reaches the steady path.)  Two full tiles and a partly
+    filled one (passenger lanes), per-burst scale, both sample types; Gardner outputs bit-exact, decisions
+    exact and the frequency <= 1e-12 / 1e-9 inside the FLL's stable horizon."""
+    import dsp_amd
+    from test_gpu_fuzz import _burst
+    rng = np.random.default_rng(900 + sps)
+    B, nsym, alpha, mu0, Bn = 130, 300, 0.05, 0.37, 0.03
+    N = nsym * sps
+    X = np.stack([_burst(rng, N, sps, 1) for _ in range(B)])
+    if c64:
+        X = X.astype(np.complex64)
+    scale = rng.uniform(0.5, 2.0, B)
+    got = dsp_amd.sync_chain_batch(X, sps, alpha, mu0, Bn, 1, scale=scale, outputs="all", ctx=ctx)
+    cdt, rdt = (np.complex64, np.float32) if c64 else (np.complex128, np.float64)
+    horizon = int(0.9 / (np.pi * 4 * Bn / 1000 / 1.25))
+    for b in range(B):
+        x = X[b].astype(np.complex128) * scale[b]
+        rec, err, mu = oracle.gardner_timing_recovery(x, sps, alpha, mu0)
+        n = len(rec)
+        assert got["n_out"][b] == n, b
+        assert np.array_equal(got["rec"][b, :n], rec.astype(cdt)), b
+        assert np.array_equal(got["mu"][b, :n - 1], mu.astype(rdt)), b
+        assert np.array_equal(got["err"][b, :n - 1], err.astype(rdt)), b
+        sl, cf, fr, ef = oracle.fll_func(rec, Bn, 1)
+        H = min(n, horizon)
+        assert np.array_equal(got["dec"][b, :H], oracle.quadrants(sl[:H])), b
+        assert np.max(np.abs(got["freq"][b, :H] - fr[:H])) < (1e-9 if c64 else 1e-12), b
