@@ -102,6 +102,121 @@ def test_fuzz_chain(ctx, oracle, trial):
                 assert np.max(np.abs(got["sig"][b, :H] - sl[:H])) < (1e-6 if c64 else 1e-9) * max(1.0, np.abs(sl[:H]).max())
 
 
+def _drifting_burst(rng, n, sps, drift):
+    """_burst's pulse train with a sampling clock that runs `drift` fast: mu walks by drift * sps per symbol
+    and wraps (a symbol slip) every 1 / drift symbols."""
+    nsym = int(n / sps * (1 + abs(drift))) + 4
+    sym = np.exp(1j * (np.pi / 4 + np.pi / 2 * rng.integers(0, 4, nsym)))
+    t = np.arange(n) / sps * (1 + drift) + rng.uniform(0, 1)
+    k = np.floor(t).astype(int)
+    f = t - k
+    x = (sym[np.clip(k, 0, nsym - 1)] * (0.5 + 0.5 * np.cos(2 * np.pi * (f - 0.5)))
+         + 0.3 * sym[np.clip(k + 1, 0, nsym - 1)] * f)
+    x = x * np.exp(1j * (2 * np.pi * rng.uniform(-1e-3, 1e-3) * np.arange(n) + rng.uniform(0, 6.28)))
+    return x + 0.05 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+
+
+@pytest.mark.parametrize("trial", range(24 * SCALE))
+def test_fuzz_steady_path(ctx, oracle, trial):
+    """The sweep above draws ragged tiles, which never reach the steady path and its speculative segments
+    (every lane active, window clear of the shortest burst's end).  Here every burst of a call is equally
+    long: full tiles plus, sometimes, a partly filled one (passenger lanes); every samples-per-symbol count,
+    loop gains up to the segments' |alpha e| < 1 evidence, start values across [-sps, sps), clocks that drift
+    so that mu wraps in mid-segment (the vote fails and the per-symbol code redoes the segment), every
+    output subset the segments are specialised for, one wave or two per tile.  Bars as above."""
+    import dsp_amd
+    rng = np.random.default_rng(7000 + trial)
+    sps = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8]))
+    B = int(rng.choice([64, 128, 130, 70]))
+    nsym = int(rng.choice([40, 150, 333, 700]))
+    N = nsym * sps + int(rng.integers(0, sps))
+    alpha = float(rng.choice([0.007, 0.002, 0.05, 0.1, 0.2]))
+    mu0 = float(rng.uniform(-sps, sps)) if rng.integers(0, 2) else 0.0
+    Bn = float(rng.choice([0.03, 0.001]))
+    drift = float(rng.choice([0.0, 0.0, 2e-3, -2e-3, 1e-2]))
+    X = np.stack([_drifting_burst(rng, N, sps, drift * rng.uniform(0.5, 1.0)) for _ in range(B)])
+    c64 = bool(rng.integers(0, 2))
+    if c64:
+        X = X.astype(np.complex64)
+    scale = rng.uniform(0.5, 2.0, B) if rng.integers(0, 2) else None
+    split = int(rng.choice([-1, -1, 0, 1]))
+    outs = [("rec", "err", "mu", "sig", "freq", "ef", "dec"), ("dec", "mu", "freq"), ("dec",), ("mu", "dec"),
+            ("rec", "err", "mu", "dec"), ("rec", "mu", "freq", "dec"), ("err", "sig", "dec")][int(rng.integers(0, 7))]
+    ctx.set_option("split", split)
+    try:
+        got = dsp_amd.sync_chain_batch(X, sps, alpha, mu0, Bn, 1, scale=scale, outputs=outs, ctx=ctx)
+    except dsp_amd.DspError as e:
+        assert e.code == -3, e                                  # gardner2.py's own loop does not end on this burst
+        b = int(str(e).split("burst ")[1].split(":")[0])
+        with pytest.raises(RuntimeError):
+            oracle.gardner_timing_recovery(X[b].astype(np.complex128) * (scale[b] if scale is not None else 1.0), sps, alpha, mu0)
+        return
+    finally:
+        ctx.set_option("split", -1)
+    cdt, rdt = (np.complex64, np.float32) if c64 else (np.complex128, np.float64)
+    horizon = int(0.9 / (np.pi * 4 * Bn / 1000 / 1.25))
+    for b in range(B):
+        x = X[b].astype(np.complex128) * (scale[b] if scale is not None else 1.0)
+        rec, err, mu = oracle.gardner_timing_recovery(x, sps, alpha, mu0)
+        n = len(rec)
+        assert got["n_out"][b] == n, (b, got["n_out"][b], n)
+        if "rec" in outs:
+            assert np.array_equal(got["rec"][b, :n], rec.astype(cdt)), b
+        if "mu" in outs:
+            assert np.array_equal(got["mu"][b, :n - 1], mu.astype(rdt)), b
+        if "err" in outs:
+            assert np.array_equal(got["err"][b, :n - 1], err.astype(rdt)), b
+        sl, cf, fr, ef = oracle.fll_func(rec, Bn, 1)
+        H = min(n, horizon)
+        assert np.array_equal(got["dec"][b, :H], oracle.quadrants(sl[:H])), b
+        if "freq" in outs:
+            assert np.max(np.abs(got["freq"][b, :H] - fr[:H])) < (1e-9 if c64 else FREQ_TOL), b
+        if "sig" in outs:
+            assert np.max(np.abs(got["sig"][b, :H] - sl[:H])) < (1e-6 if c64 else 1e-9) * max(1.0, np.abs(sl[:H]).max()), b
+
+
+@pytest.mark.parametrize("trial", range(8 * SCALE))
+def test_fuzz_steady_path_lagrange(ctx, oracle, trial):
+    """The same for the Lagrange interpolator inside the timing loop of the two-wave kernel (both loops run):
+    every order 1 ... 8, samples-per-symbol counts other than 4 too (the straight-line iteration shares its ring
+    reads between the three instants at 4 only), full tiles of equally long bursts, against the restated loop
+    of tests/test_gpu_lagrange.py to its bar; the decisions of the bursts that are compared follow fll_func
+    on the restated loop's symbols."""
+    import dsp_amd
+    from test_gpu_lagrange import gardner2_lagrange_restated
+    rng = np.random.default_rng(7700 + trial)
+    sps = int(rng.choice([2, 3, 4, 5, 6, 8]))
+    half = int(rng.integers(1, 9))
+    B = int(rng.choice([64, 130]))
+    nsym = int(rng.choice([60, 200]))
+    N = nsym * sps
+    alpha = float(rng.choice([0.007, 0.02, 0.05]))
+    drift = float(rng.choice([0.0, 2e-3, -5e-3]))
+    X = np.stack([_drifting_burst(rng, N, sps, drift) for _ in range(B)])
+    c64 = bool(rng.integers(0, 2))
+    Xd = X.astype(np.complex64) if c64 else X
+    split = int(rng.choice([-1, -1, 0]))
+    ctx.set_option("split", split)
+    try:
+        got = dsp_amd.sync_chain_batch(Xd, sps, alpha, 0.0, 0.03, 1, interp_half_len=half,
+                                       outputs=("rec", "err", "mu", "dec", "freq"), ctx=ctx)
+    finally:
+        ctx.set_option("split", -1)
+    tol = 1e-6 if c64 else 1e-11
+    for b in (0, 13, 63, B - 1):
+        rec, err, mu = gardner2_lagrange_restated(oracle, Xd[b].astype(np.complex128), sps, alpha, half)
+        n = int(got["n_out"][b])
+        assert n == len(rec), (b, n, len(rec))
+        assert np.max(np.abs(got["mu"][b, :n - 1] - mu), initial=0) < tol, b
+        assert np.max(np.abs(got["err"][b, :n - 1] - err), initial=0) < tol * max(1.0, np.abs(err).max()), b
+        assert np.max(np.abs(got["rec"][b, :n] - rec)) < tol * max(1.0, np.abs(rec).max()), b
+        if not c64:
+            out = oracle.fll_func(rec, 0.03, 1)
+            # decisions of symbols that are not within the loop's own 1e-11 of a slicer boundary
+            safe = np.minimum(np.abs(out[0].real), np.abs(out[0].imag)) > 1e-8
+            assert np.array_equal(got["dec"][b, :n][safe], oracle.quadrants(out[0])[safe]), b
+
+
 @pytest.mark.parametrize("trial", range(32 * SCALE))
 def test_fuzz_fir(ctx, oracle, trial):
     """Matched filter + /np.std over random tap counts (LDS-tiled kernel and the direct form for long
