@@ -273,3 +273,36 @@ def test_spec_segments_odd_sps(ctx, oracle, sps, c64):
         H = min(n, horizon)
         assert np.array_equal(got["dec"][b, :H], oracle.quadrants(sl[:H])), b
         assert np.max(np.abs(got["freq"][b, :H] - fr[:H])) < (1e-9 if c64 else 1e-12), b
+
+
+@pytest.mark.parametrize("c64", [True, False])
+def test_fll_blocks_with_axis_and_zero_samples(ctx, oracle, c64):
+    """A full tile on the steady path in which some lanes carry samples the FLL wave's fast step does not
+    handle (np.sign(0) = 0: a real-valued burst keeps an exactly zero imaginary part through the whole chain
+    while the frequency estimate is 0; an all-zero burst; an imaginary-valued one): the block's evidence word
+    sends such blocks through the reference-order step, and every lane -- the ordinary ones too -- must come
+    out as the oracle has it."""
+    import dsp_amd
+    from test_gpu_fuzz import _burst
+    rng = np.random.default_rng(77)
+    sps, nsym, B = 4, 260, 64
+    N = sps * nsym
+    X = np.stack([_burst(rng, N, sps, 1) for _ in range(B)])
+    X[5] = X[5].real
+    X[9] = 0
+    X[17] = 1j * X[17].imag
+    X[33, 400:] = X[33, 400:].real                      # turns degenerate in mid-burst: only while freq is still 0 it stays so
+    if c64:
+        X = X.astype(np.complex64)
+    got = dsp_amd.sync_chain_batch(X, sps, 0.007, 0.0, 0.03, 1, outputs="all", ctx=ctx)
+    cdt, rdt = (np.complex64, np.float32) if c64 else (np.complex128, np.float64)
+    for b in range(B):
+        rec, err, mu = oracle.gardner_timing_recovery(X[b].astype(np.complex128), sps, 0.007, 0.0)
+        n = len(rec)
+        assert got["n_out"][b] == n, b
+        assert np.array_equal(got["rec"][b, :n], rec.astype(cdt)), b
+        assert np.array_equal(got["mu"][b, :n - 1], mu.astype(rdt)), b
+        sl, cf, fr, ef = oracle.fll_func(rec, 0.03, 1)
+        assert np.array_equal(got["dec"][b, :n], oracle.quadrants(sl)), b
+        assert np.max(np.abs(got["freq"][b, :n] - fr)) < (1e-9 if c64 else 1e-12), b
+        assert np.max(np.abs(got["sig"][b, :n] - sl)) < (1e-6 if c64 else 1e-9) * max(1.0, np.abs(sl).max()), b
