@@ -23,10 +23,15 @@ __global__ __launch_bounds__(128) void k(const uint8_t *x, uint8_t *rec, uint8_t
     const int lane = threadIdx.x & 63, role = threadIdx.x >> 6, tile = blockIdx.x;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
     float acc = lane;
+    // var & 32: the seven output streams of a tile lie back to back in ONE buffer (rec), 2112 bytes per row
+    // in all -- a tile then touches 3 two-MiB pages instead of 7 (does address translation limit the rate?)
+    const bool grouped = (var & 32) != 0;
+    const size_t tb = (size_t)out_rows * 2112;
     if (role == 0) {
         const uint8_t *xt = x + (size_t)tile * in_rows * 512 + lane * 16;
-        const uint8_t *rt = rec + (size_t)tile * out_rows * 512, *et = err + (size_t)tile * out_rows * 256,
-                      *mt = mu + (size_t)tile * out_rows * 256;
+        const uint8_t *rt = grouped ? rec + tile * tb : rec + (size_t)tile * out_rows * 512,
+                      *et = grouped ? rec + tile * tb + (size_t)out_rows * 512 : err + (size_t)tile * out_rows * 256,
+                      *mt = grouped ? rec + tile * tb + (size_t)out_rows * 768 : mu + (size_t)tile * out_rows * 256;
         int F = 0;   // pieces (1 KiB = 2 rows) issued
         for (int it0 = 0; it0 < n_sym; it0 += T) {
             if (mode & 1) {
@@ -89,8 +94,10 @@ __global__ __launch_bounds__(128) void k(const uint8_t *x, uint8_t *rec, uint8_t
             }
         }
     } else {
-        const uint8_t *st = sig + (size_t)tile * out_rows * 512, *ft = fr + (size_t)tile * out_rows * 256,
-                      *et = ef + (size_t)tile * out_rows * 256, *dt = dec + (size_t)tile * out_rows * 64;
+        const uint8_t *st = grouped ? rec + tile * tb + (size_t)out_rows * 1024 : sig + (size_t)tile * out_rows * 512,
+                      *ft = grouped ? rec + tile * tb + (size_t)out_rows * 1536 : fr + (size_t)tile * out_rows * 256,
+                      *et = grouped ? rec + tile * tb + (size_t)out_rows * 1792 : ef + (size_t)tile * out_rows * 256,
+                      *dt = grouped ? rec + tile * tb + (size_t)out_rows * 2048 : dec + (size_t)tile * out_rows * 64;
         for (int it = 0; it < n_sym; it++) {
             for (int s = 0; s < spin; s++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(acc));
             if ((mode & 4) && (var & 24)) {
@@ -165,7 +172,7 @@ int main(int argc, char **argv)
     const size_t esz[7] = {16, 4, 4, 16, 4, 4, 1};
     CHECK(hipMalloc(&x, (size_t)ntiles * in_rows * 512 + 65536));
     CHECK(hipMemset(x, 1, (size_t)ntiles * in_rows * 512));
-    for (int i = 0; i < 7; i++) CHECK(hipMalloc(&o[i], (size_t)ntiles * out_rows * 64 * esz[i]));
+    for (int i = 0; i < 7; i++) CHECK(hipMalloc(&o[i], (size_t)ntiles * out_rows * 64 * esz[i] * (i == 0 ? 3 : 1)));   // (o[0] also holds the grouped layout)
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     const int lds = 40960;
@@ -187,7 +194,7 @@ int main(int argc, char **argv)
         }
         CHECK(hipFree(y));
     }
-    for (int var : {0, 2, 3}) { const int spin = 0;   // 2: nt loads, 3: nt loads + nt stores
+    for (int var : {0, 2, 3, 32}) { const int spin = 0;   // 2: nt loads, 3: nt loads + nt stores, 32: a tile's output streams contiguous
         for (int mode : {1, 6, 7}) {
             for (int r = 0; r < 2; r++) {
                 hipLaunchKernelGGL(k, dim3(ntiles), dim3(128), lds, 0, x, o[0], o[1], o[2], o[3], o[4], o[5], o[6],
