@@ -32,22 +32,24 @@ def _signal(rng, n, offs, pre, sps, dtype):
 
 
 CASES = [
-    # B, n_pkt, n_taps, cfo_method
-    (200, 1792, 41, 1),      # 3 full tiles through the strips + 8 bursts through the chunk kernel
-    (130, 2048, 41, 3),
-    (70, 1001, 41, 2),       # odd packet length: no two-sample pieces for complex64
-    (5, 1600, 33, 1),        # fewer bursts than lanes
-    (128, 1200, 31, 0),      # start = 15: odd, the strips' pieces would straddle the burst's first sample
-    (64, 960, 21, 0),
+    # B, n_pkt, n_taps, cfo_method, sps
+    (200, 1792, 41, 1, 4),   # 3 full tiles through the strips + 8 bursts through the chunk kernel
+    (130, 2048, 41, 3, 4),
+    (70, 1001, 41, 2, 4),    # odd packet length: no two-sample pieces for complex64
+    (5, 1600, 33, 1, 4),     # fewer bursts than lanes
+    (128, 1200, 31, 0, 4),   # start = 15: odd, the strips' pieces would straddle the burst's first sample
+    (64, 960, 21, 0, 4),
+    (130, 1200, 31, 1, 3),   # odd samples-per-symbol counts: the whole flow, and full tiles on the recurrence's
+    (128, 1500, 41, 2, 5),   #   steady path behind it (RRC span 10 at 3 sps = 31 taps, span 8 at 5 sps = 41)
 ]
 
 
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
-@pytest.mark.parametrize("B,n_pkt,n_taps,method", CASES)
-def test_fused_front_end_is_bit_identical(dtype, B, n_pkt, n_taps, method):
+@pytest.mark.parametrize("B,n_pkt,n_taps,method,sps", CASES)
+def test_fused_front_end_is_bit_identical(dtype, B, n_pkt, n_taps, method, sps):
     import dsp_amd
     rng = np.random.default_rng(B * 7 + n_pkt)
-    sps, L = 4, 48
+    L = 48
     n = 60000 + n_pkt
     pre = np.exp(1j * (np.pi / 4 + np.pi / 2 * rng.integers(0, 4, L)))
     offs = np.sort(rng.integers(0, n - n_pkt, B)).astype(np.int64)
@@ -56,7 +58,8 @@ def test_fused_front_end_is_bit_identical(dtype, B, n_pkt, n_taps, method):
     offs[-1] = n - n_pkt                             # the last burst ends with the signal
     offs[0] = 0
     x = _signal(rng, n, offs, pre, sps, dtype)
-    h = np.ascontiguousarray(dsp_amd.rrc_filter(sps, 10, 0.35)[(41 - n_taps) // 2:][:n_taps])
+    full = dsp_amd.rrc_filter(sps, 8 if sps == 5 else 10, 0.35)
+    h = np.ascontiguousarray(full[(len(full) - n_taps) // 2:][:n_taps])
     assert len(h) == n_taps
     kw = dict(f_rel=rng.uniform(-3e-3, 3e-3, B)) if method == 0 else dict(cfo_method=method)
     ctx = dsp_amd.Context(0)
