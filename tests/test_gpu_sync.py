@@ -306,3 +306,31 @@ def test_fll_blocks_with_axis_and_zero_samples(ctx, oracle, c64):
         assert np.array_equal(got["dec"][b, :n], oracle.quadrants(sl)), b
         assert np.max(np.abs(got["freq"][b, :n] - fr)) < (1e-9 if c64 else 1e-12), b
         assert np.max(np.abs(got["sig"][b, :n] - sl)) < (1e-6 if c64 else 1e-9) * max(1.0, np.abs(sl).max()), b
+
+
+@pytest.mark.parametrize("sps", [10, 12, 16, 25, 64])
+def test_large_sps(ctx, oracle, sps):
+    """Samples-per-symbol counts beyond the sweeps' 1 ... 8 (the C-ABI takes up to 1024): the ring plan shrinks
+    its block to one or two symbols and then gives the ring up (rows straight from global memory); a full
+    tile and a ragged one, against the oracle with the usual bars."""
+    import dsp_amd
+    from test_gpu_fuzz import _burst
+    rng = np.random.default_rng(300 + sps)
+    nsym, B = 90, 70
+    N = sps * nsym
+    X = np.stack([_burst(rng, N, sps, 1) for _ in range(B)])
+    lens = np.full(B, N, np.int32)
+    lens[64:] = rng.integers(2 * sps, N, B - 64)
+    for b in range(64, B):
+        X[b, lens[b]:] = 0
+    got = dsp_amd.sync_chain_batch(X, sps, 0.02, 0.0, 0.03, 1, lens=lens, outputs="all", ctx=ctx)
+    for b in range(B):
+        rec, err, mu = oracle.gardner_timing_recovery(X[b, :lens[b]], sps, 0.02, 0.0)
+        n = len(rec)
+        assert got["n_out"][b] == n, b
+        assert np.array_equal(got["rec"][b, :n], rec), b
+        assert np.array_equal(got["mu"][b, :n - 1], mu), b
+        assert np.array_equal(got["err"][b, :n - 1], err), b
+        sl, cf, fr, ef = oracle.fll_func(rec, 0.03, 1)
+        assert np.array_equal(got["dec"][b, :n], oracle.quadrants(sl)), b
+        assert np.max(np.abs(got["freq"][b, :n] - fr)) < 1e-12, b
