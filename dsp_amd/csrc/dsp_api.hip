@@ -381,8 +381,8 @@ int dsp_set_option(dsp_ctx *c, const char *name, int64_t value)
         c->lds_pad = (int)value;
     } else if (!strcmp(name, "split")) {
         c->split = (int)value;
-    } else if (!strcmp(name, "batch_split")) {
-        c->batch_split = value != 0;
+    } else if (!strcmp(name, "batch_split")) {          // 0: never; 1: at the kernel's register-limited residency; n > 1: at n tiles per CU
+        c->batch_split = (int)value;
 #ifdef DSP_TRACE
     } else if (!strcmp(name, "trace_ptr")) {     // diagnostic build: device buffer for wave stamps
         c->trace = (unsigned long long *)(uintptr_t)value;
@@ -597,14 +597,21 @@ static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, c
         return fail(DSP_E_ARG, "sync: interp_half_len must be in [0,8]");
     if (fll && !(a->y > 0.0)) return fail(DSP_E_ARG, "sync: y must be > 0");
 
-    // More tiles than a CU keeps resident (as far as the kernel's registers go: four two-wave tiles at the
-    // linear kernel's 192 VGPRs, read from the code object): the surplus would run as a second, poorly filled
+    // More tiles than a CU keeps resident (as far as the kernel's registers go, read from the code object --
+    // the Lagrange kernels hold up to 281 -- and at most four, see below): the surplus would run as a second, poorly filled
     // round (98 304 bursts: 4.4 ms against 2 x 1.4).  Such a batch goes out as equal launches of whole tiles
     // instead, each of at most that many tiles per CU; the bursts are independent, so only the pointers move.
     {
         const int64_t ntiles_all = (a->B + 63) / 64;
-        const int per_cu_max = (fll && a->variant != 2 && a->interp_half_len == 0)
-                                   ? sync_split_tiles_per_cu(a->dtype == DSP_C128, a->variant, a->scale != nullptr) : 4;
+        // ... and at most four: beyond that a tile's LDS share (160 KiB / tiles) no longer holds the 64-row ring
+        // and its queue, and the small-ring shape is the slower one whatever the registers allow (the kernel has
+        // needed 168 VGPRs = six tiles per CU since the constants' loads are pinned, sync_kernels.hip
+        // load_math_consts; one launch of five tiles per CU: 4.07 ms against 2.40 as 3 + 2; six: 2.84 / 2.78;
+        // twelve as 6 + 6: 5.52 / 5.28 as 4 + 4 + 4 -- profiles/r03_s3_ab_experiments.txt)
+        int per_cu_max = c->batch_split > 1 ? c->batch_split
+                       : (fll && a->variant != 2 && a->interp_half_len == 0)
+                             ? sync_split_tiles_per_cu(a->dtype == DSP_C128, a->variant, a->scale != nullptr) : 4;
+        if (c->batch_split == 1 && per_cu_max > 4) per_cu_max = 4;
         const int64_t resident = (int64_t)c->n_cu * per_cu_max;
         if (ntiles_all > resident && c->batch_split != 0) {
             const int64_t nlaunch = (ntiles_all + resident - 1) / resident;
@@ -723,7 +730,9 @@ static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, c
         // eight.  At four tiles per CU (40 KiB each: 32 KiB ring + three-symbol queue) they would leave the
         // queue one symbol, so that shape keeps the masked addresses.
         P.guard_rows = 0;
-        if (c->guard != 0 && c->spec && P.use_ring && a->variant == DSP_GARDNER2 && P.half_len == 0 && sps + 2 <= 8) {
+        // (speculative segments: gardner2, and gardner_ted at even samples-per-symbol counts)
+        const bool spec_variant = a->variant == DSP_GARDNER2 || (a->variant == DSP_GARDNER_TED && sps >= 2 && (sps & 1) == 0);
+        if (c->guard != 0 && c->spec && P.use_ring && spec_variant && P.half_len == 0 && sps + 2 <= 8) {
             const size_t gbytes = (size_t)8 * 64 * elem;
             if (lds + gbytes + (size_t)2 * 4 * 64 * 17 + 16 <= room) { P.guard_rows = 8; lds += gbytes; }
         }
@@ -738,7 +747,7 @@ static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, c
         // the queue block, whichever comes first, and every segment costs a vote and a hand-over: keep the
         // two block lengths multiples of one another and the shorter one as long as the LDS share allows
         // (16384 bursts: T 8 / TQ 7 -> segments of 7, 1, 6, 2 ... symbols, 1.03 ms; T 7 / TQ 7: 0.99 ms).
-        if (c->queue_block == 0 && c->spec && P.use_ring && a->variant == DSP_GARDNER2 && P.half_len == 0) {
+        if (c->queue_block == 0 && c->spec && P.use_ring && spec_variant && P.half_len == 0) {
             const int rpp = 1024 / (64 * elem);
             int best_n = 0, best_T = P.T, best_TQ = TQ;
             for (int tq = TQ; tq >= 1; tq--)
@@ -754,7 +763,7 @@ static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, c
             }
         }
         P.TQ = TQ;
-        P.dma_fll = (c->dma_fll != 0 && c->spec && P.use_ring && a->variant == DSP_GARDNER2 && P.half_len == 0 &&
+        P.dma_fll = (c->dma_fll != 0 && c->spec && P.use_ring && spec_variant && P.half_len == 0 &&
                      P.T % TQ == 0) ? 1 : 0;
         // From three tiles per CU on two or more waves share a SIMD and the arbiter's oldest-first choice lets
         // some run ahead while others starve; rotating the four priority levels over the wave slots every 8

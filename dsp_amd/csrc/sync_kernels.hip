@@ -251,6 +251,12 @@ __device__ __forceinline__ dspm::MathK load_math_consts()
     dspm::MathK k;
 #pragma unroll
     for (int i = 0; i < dspm::K_COUNT; i++) k.v[i] = k_math_table[z + i];
+    // An empty asm is a use: the compiler's s_waitcnt for these loads lands HERE.  Left to the first real use
+    // it can land inside a block loop (the gardner_ted kernels have no FLL step in front of theirs), and as the
+    // asm stores are invisible to the compiler's count it comes out as vmcnt(0) there: every symbol then waits
+    // for all of the wave's stores (16 384 gardner_ted bursts, all outputs: 0.99 ms instead of 0.78).
+#pragma unroll
+    for (int i = 0; i < dspm::K_COUNT; i++) asm volatile("" : "+v"(k.v[i]));
     return k;
 }
 
@@ -695,6 +701,113 @@ __device__ __forceinline__ bool g2_spec_segment(const Tile<IN> &tl, dspm::GState
     if (__any(bad)) return false;
     gs.mu = mu;
     gs.k += tc.sps * n;
+    return true;
+}
+
+// The same for the gardner_ted variant (hw1/gardner.py:45-72), even samples-per-symbol counts: the loop has no
+// symbol slips (mu is clipped to [-sps, sps] instead) and puts out x_k, the sample at the OLD mu, which the TED
+// needs anyway -- no output interpolation.  Assumptions on the evidence words: the clip inactive (|mu| < sps
+// before and after every update), idx_k and idx_next in one binade (then idx_mid = idx_k + sps/2 -- a whole
+// number of samples for even sps -- and idx_next = idx_k + sps hold exactly: one floor and one fraction serve all
+// three; odd sps put the mid instant half a sample off and stay with the per-symbol code), the rows inside the
+// ring window, |delta_mu * e| < 1 (so that the instants grow from symbol to symbol and the first and the last
+// bound them all).  idx_k >= win_lo > 0, so np.floor is the truncation.  The caller guarantees that every lane
+// has at least n more symbols to run (k + n <= (len - 2 sps) // sps; :52's break cannot fire before that for
+// sps >= 2).  Same values as ted_iter / timing_iter bit for bit; state untouched when the vote fails.
+template <typename IN, bool SC, int MASK, bool GUARD>
+__device__ __forceinline__ bool ted_spec_segment(const Tile<IN> &tl, dspm::GState &gs, const TimingConst &tc,
+                                                 const int n, const int it0, const SpecBases &sb,
+                                                 const unsigned lane_s, const unsigned lane_c, const unsigned q_addr)
+{
+    typedef typename InT<IN>::OS OS;
+    typedef typename InT<IN>::OC OC;
+    typedef GroupStore<OC> GS;
+    constexpr unsigned ROWB = 64u * (unsigned)sizeof(IN);
+    const unsigned rmask = (unsigned)tl.R * ROWB - 1u;
+    const unsigned colb = tl.lds_base + (unsigned)tl.col * (unsigned)sizeof(IN);
+    const double delta = tc.alpha, spsd = tc.spsd, scale = tl.scale;
+    const int win_lo = tl.win_lo;
+    const int wlim = tl.win_hi - win_lo - (tc.sps + 2);  // rows r_k .. r_k + sps + 1 inside [win_lo, win_hi)
+    const unsigned midb = (unsigned)(tc.sps / 2) * ROWB, lateb = (unsigned)tc.sps * ROWB;
+    double mu = gs.mu;
+    double base = (double)(gs.k * tc.sps), basen = (double)((gs.k + 1) * tc.sps);     // :47-48, whole numbers
+    unsigned acc_w = 0u, acc_mu = 0u, acc_e = 0u;
+    unsigned row_s = (unsigned)it0 * 64u * (unsigned)sizeof(OS) + lane_s;
+    unsigned row_c = (unsigned)it0 * 64u * (unsigned)sizeof(OC) + lane_c;            // (row of symbol it: ROFF = 0)
+    unsigned qa = q_addr;
+    const unsigned mu_lim = (unsigned)__double2hiint(spsd);
+    IN e0, e1, m0, m1, l0, l1;                           // rows k, k+1, mid, mid+1, next, next+1
+    double i_a = 0.0;
+    unsigned ev_mu = 0u, hi_c = 0u, w_cur = 0u;
+
+    auto issue = [&]() {
+        i_a = base + mu;                                 // idx_k, hw1/gardner.py:47
+        const double i_c = basen + mu;                   // idx_next, :48
+        const int r_a = __double2int_rz(i_a);
+        hi_c = (unsigned)__double2hiint(i_c);
+        w_cur = (unsigned)(r_a - win_lo);
+        ev_mu = (unsigned)__double2hiint(mu) & 0x7fffffffu;
+        const unsigned rb = (unsigned)r_a * ROWB;
+        if (GUARD) {
+            const unsigned a0 = (rb & rmask) | colb;
+            const unsigned am = a0 + midb, al = a0 + lateb;
+            e0 = lds_ld<IN>(a0);
+            e1 = lds_ld<IN>(a0 + ROWB);
+            m0 = lds_ld<IN>(am);
+            m1 = lds_ld<IN>(am + ROWB);
+            l0 = lds_ld<IN>(al);
+            l1 = lds_ld<IN>(al + ROWB);
+        } else {
+            e0 = lds_ld<IN>((rb & rmask) | colb);
+            e1 = lds_ld<IN>(((rb + ROWB) & rmask) | colb);
+            m0 = lds_ld<IN>(((rb + midb) & rmask) | colb);
+            m1 = lds_ld<IN>(((rb + midb + ROWB) & rmask) | colb);
+            l0 = lds_ld<IN>(((rb + lateb) & rmask) | colb);
+            l1 = lds_ld<IN>(((rb + lateb + ROWB) & rmask) | colb);
+        }
+    };
+
+    issue();
+    const unsigned hi_first = (unsigned)__double2hiint(i_a);
+    acc_w = w_cur;
+    unsigned hi_last = 0u, w_last = 0u;
+    for (int s = 0; s < n; s++) {
+        hi_last = hi_c; w_last = w_cur;
+        acc_mu = ev_mu > acc_mu ? ev_mu : acc_mu;
+        const double f = dspm::fract_pos(i_a);           // == the fraction of idx_mid and of idx_next, see above
+        const cd xa = dspm::lerp(widen<IN, SC>(e0, scale), widen<IN, SC>(e1, scale), f);
+        const cd xb = dspm::lerp(widen<IN, SC>(m0, scale), widen<IN, SC>(m1, scale), f);
+        const cd xc = dspm::lerp(widen<IN, SC>(l0, scale), widen<IN, SC>(l1, scale), f);
+        const double e = dspm::ted_error(xa, xb, xc);    // :61
+        const double de = delta * e;
+        const unsigned ah = (unsigned)__double2hiint(de) & 0x7fffffffu;
+        acc_e = ah > acc_e ? ah : acc_e;
+        const double mu_h = mu, pos = i_a;               // :63 mu_history holds the old mu; x_k sits at idx_k
+        mu = mu + de;                                    // :66 (the clip of :69 is inactive: acc_mu)
+        base += spsd; basen += spsd;
+        issue();
+        const OC rv = {(OS)xa.re, (OS)xa.im};            // :72
+        if (MASK == 7) GS::c_s_s(row_c, rv, sb.rec_t, row_s, (OS)e, sb.err_t, (OS)mu_h, sb.mu_t);
+        else if (MASK == 15) GS::c_s_s_s(row_c, rv, sb.rec_t, row_s, (OS)e, sb.err_t, (OS)mu_h, sb.mu_t, (OS)pos, sb.pos_t);
+        else if (MASK == 12) GS::s_s(row_s, (OS)mu_h, sb.mu_t, (OS)pos, sb.pos_t);
+        else if (MASK == 4) GS::s(row_s, (OS)mu_h, sb.mu_t);
+        else if (MASK != 0) {
+            if (sb.rec_t) sst(sb.rec_t, row_c, rv);
+            if (sb.err_t) sst(sb.err_t, row_s, (OS)e);
+            if (sb.mu_t) sst(sb.mu_t, row_s, (OS)mu_h);
+            if (sb.pos_t) sst(sb.pos_t, row_s, (OS)pos);
+        }
+        const d2v qv = {xa.re, xa.im};
+        lds_st<d2v>(qa, qv);
+        row_s += 64u * (unsigned)sizeof(OS); row_c += 64u * (unsigned)sizeof(OC); qa += 1024u;
+    }
+    acc_mu = ev_mu > acc_mu ? ev_mu : acc_mu;            // the mu the segment leaves behind was not clipped either
+    const unsigned acc_x = hi_first ^ hi_last;
+    acc_w = w_last > acc_w ? w_last : acc_w;
+    const bool bad = (acc_x >> 20) != 0u || acc_w > (unsigned)wlim || acc_mu >= mu_lim || acc_e >= 0x3ff00000u;
+    if (__any(bad)) return false;
+    gs.mu = mu;
+    gs.k += n;
     return true;
 }
 
@@ -1207,7 +1320,14 @@ __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void 
         int min_len = len;
         for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(min_len, d); min_len = o < min_len ? o : min_len; }
         min_len = __builtin_amdgcn_readfirstlane(min_len);
-        const bool steady_ok = VARIANT == DSP_VARIANT_GARDNER2 && ring;
+        // (gardner_ted: the speculative segments are its whole steady path -- even samples-per-symbol counts)
+        const bool ted_even = VARIANT == DSP_VARIANT_TED && sps >= 2 && (sps & 1) == 0;
+        const bool steady_ok = ring && (VARIANT == DSP_VARIANT_GARDNER2 || (ted_even && H == 0 && P.spec != 0));
+        int min_nsym = tc.n_symbols;                    // gardner_ted: symbols the tile's shortest burst runs
+        if (VARIANT == DSP_VARIANT_TED) {
+            for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(min_nsym, d); min_nsym = o < min_nsym ? o : min_nsym; }
+            min_nsym = __builtin_amdgcn_readfirstlane(min_nsym);
+        }
         bool all_active = __all(gs.active);
         const unsigned char *rec_t = (const unsigned char *)(o_rec + (size_t)tile * out_rows * 64);
         const unsigned char *err_t = (const unsigned char *)(o_terr + (size_t)tile * out_rows * 64);
@@ -1217,9 +1337,9 @@ __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void 
         int n_steady = 0;
         // speculative segments (g2_spec_segment): gardner2 with the linear interpolator, ring in use and
         // starting on a multiple of its size
-        constexpr bool SPEC = (SPECT && VARIANT == DSP_VARIANT_GARDNER2 && H == 0);
+        constexpr bool SPEC = (SPECT && H == 0 && (VARIANT == DSP_VARIANT_GARDNER2 || VARIANT == DSP_VARIANT_TED));
         const int tmask = (o_rec ? 1 : 0) | (o_terr ? 2 : 0) | (o_mu ? 4 : 0) | (o_pos ? 8 : 0);
-        const bool spec_cfg = SPEC && ring && P.spec != 0 &&
+        const bool spec_cfg = SPEC && ring && P.spec != 0 && (VARIANT == DSP_VARIANT_GARDNER2 || ted_even) &&
                               (tl.lds_base & ((unsigned)tl.R * 64u * (unsigned)sizeof(IN) - 1u)) == 0u;
         const SpecBases sbases = {o_rec ? rec_t : nullptr, o_terr ? err_t : nullptr, o_mu ? mu_t : nullptr,
                                   o_pos ? pos_t : nullptr};
@@ -1239,9 +1359,10 @@ __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void 
             // the steady path's stores address a row by a 32-bit byte offset from the tile's base: a
             // block whose last row would pass 4 GiB (row 2^22 of a complex128 output) takes the
             // size_t path below instead
-            bool steady = steady_ok && all_active && tl.win_lo > 0 && tl.win_hi + 2 * sps + 1 <= min_len &&
-                          it + T + ROFF < cap_rows &&
-                          (unsigned long long)(it + T + ROFF + 1) * 64ull * sizeof(OC) <= 0xffffffffull;
+            bool steady = steady_ok && all_active && tl.win_lo > 0 && it + T + ROFF < cap_rows &&
+                          (unsigned long long)(it + T + ROFF + 1) * 64ull * sizeof(OC) <= 0xffffffffull &&
+                          (VARIANT == DSP_VARIANT_GARDNER2 ? tl.win_hi + 2 * sps + 1 <= min_len
+                                                           : (spec_cfg && it + T <= min_nsym));
             int t = 0;
             while (t < T) {
                 // a segment ends with the DMA block or the queue block, whichever comes first
@@ -1251,7 +1372,11 @@ __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void 
                     const unsigned qa = q_lds + (unsigned)(buf * TQ + tq) * 1024u;
                     DSP_TR(trp, 10);
                     DSP_TT(tt_e);
-#define DSP_SEG(M, G) seg_done = g2_spec_segment<IN, SC, M, G>(tl, gs, tc, n, it, ROFF, sbases, lane_s, lane_c, qa)
+#define DSP_SEG(M, G)                                                                                            \
+    do {                                                                                                         \
+        if constexpr (VARIANT == DSP_VARIANT_TED) seg_done = ted_spec_segment<IN, SC, M, G>(tl, gs, tc, n, it, sbases, lane_s, lane_c, qa); \
+        else seg_done = g2_spec_segment<IN, SC, M, G>(tl, gs, tc, n, it, ROFF, sbases, lane_s, lane_c, qa);     \
+    } while (0)
                     if (tl.guard) {
                         switch (tmask) {
                             case 7: DSP_SEG(7, true); break;
@@ -1288,7 +1413,7 @@ __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void 
                     for (int i = 0; i < n; i++, t++, it++, tq++) {
                         DSP_TR(trp, 0);
                         bool done = false;
-                        if (steady && (!SPEC || !spec_cfg)) {
+                        if (VARIANT == DSP_VARIANT_GARDNER2 && steady && (!SPEC || !spec_cfg)) {
                             cd rec; double e, ps;
                             if constexpr (H > 0) done = g2_steady_lagr<IN, SC, H>(tl, gs, tc, Lp, rec, e, ps);
                             else done = g2_steady<IN, SC>(tl, gs, tc, rec, e, ps);
@@ -1361,6 +1486,9 @@ __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void 
             const double f_s = __shfl(freq, src), g_s = __shfl(integ, src), i_s = __shfl(i0, src);
             if (pass) { freq = f_s; integ = g_s; i0 = i_s; }
         }
+        // (the start values come from memory: like the constants below they are "used" here, in front of the
+        //  block loops, so that no s_waitcnt vmcnt for them ends up inside -- see load_math_consts)
+        asm volatile("" : "+v"(freq), "+v"(integ), "+v"(i0));
         const double kp = P.kp, ki = P.ki;
         const dspm::MathK MK = load_math_consts();
         OC *o_sig = (OC *)P.sig; OS *o_freq = (OS *)P.freq; OS *o_ef = (OS *)P.ef;
@@ -1398,7 +1526,7 @@ __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void 
         int it = 0;
         prio_n = prio_n ? (prio_n * T / TQ > 0 ? prio_n * T / TQ : 1) : 0;     // same period in queue blocks
         prio_c = 1;
-        constexpr bool SPEC = (SPECT && VARIANT == DSP_VARIANT_GARDNER2 && H == 0);
+        constexpr bool SPEC = (SPECT && H == 0 && (VARIANT == DSP_VARIANT_GARDNER2 || VARIANT == DSP_VARIANT_TED));
         const int fmask = (o_sig ? 1 : 0) | (o_freq ? 2 : 0) | (o_ef ? 4 : 0) | (o_dec ? 8 : 0);
         const size_t tile_el = (size_t)tile * out_rows * 64;
         const SpecBasesF fbases = {o_sig ? (const unsigned char *)(o_sig + tile_el) : nullptr,
@@ -1644,8 +1772,9 @@ static hipError_t launch_in(const SyncParams &P, int variant, bool fll, size_t l
 }
 
 // Two-wave tiles of the linear-interpolator kernel a CU can hold as far as its registers go: read from the
-// code object (the speculative segments raised the kernel from 133 to 192 VGPRs, i.e. from six tiles per CU
-// to four -- a number that must not live in the host code as a constant).
+// code object (round 2's kernel held 133 VGPRs, the speculative segments raised it to 192, pinning the loads of
+// the constants brought it back to 168: six, four, six tiles per CU -- a number that must not live in the host
+// code as a constant; the LDS shares cap the useful number at four, dsp_api.hip sync_tiles_run).
 int sync_split_tiles_per_cu(bool c128, int variant, bool scaled)
 {
     void (*k)(SyncParams);

@@ -116,22 +116,24 @@ def _drifting_burst(rng, n, sps, drift):
     return x + 0.05 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
 
 
-@pytest.mark.parametrize("trial", range(24 * SCALE))
+@pytest.mark.parametrize("trial", range(32 * SCALE))
 def test_fuzz_steady_path(ctx, oracle, trial):
     """The sweep above draws ragged tiles, which never reach the steady path and its speculative segments
     (every lane active, window clear of the shortest burst's end).  Here every burst of a call is equally
-    long: full tiles plus, sometimes, a partly filled one (passenger lanes); every samples-per-symbol count,
-    loop gains up to the segments' |alpha e| < 1 evidence, start values across [-sps, sps), clocks that drift
-    so that mu wraps in mid-segment (the vote fails and the per-symbol code redoes the segment), every
-    output subset the segments are specialised for, one wave or two per tile.  Bars as above."""
+    long: full tiles plus, sometimes, a partly filled one (passenger lanes); both timing-loop variants, every
+    samples-per-symbol count, loop gains up to the segments' |alpha e| < 1 evidence (and, for gardner_ted, gains
+    that drive mu into its clip), start values across [-sps, sps), clocks that drift so that mu wraps in
+    mid-segment (the vote fails and the per-symbol code redoes the segment), every output subset the segments
+    are specialised for, one wave or two per tile.  Bars as above."""
     import dsp_amd
     rng = np.random.default_rng(7000 + trial)
     sps = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8]))
+    variant = int(rng.integers(0, 2))
     B = int(rng.choice([64, 128, 130, 70]))
     nsym = int(rng.choice([40, 150, 333, 700]))
     N = nsym * sps + int(rng.integers(0, sps))
-    alpha = float(rng.choice([0.007, 0.002, 0.05, 0.1, 0.2]))
-    mu0 = float(rng.uniform(-sps, sps)) if rng.integers(0, 2) else 0.0
+    alpha = float(rng.choice([0.007, 0.002, 0.05, 0.1, 0.2] + ([0.8] if variant else [])))
+    mu0 = float(rng.uniform(-sps, sps)) if (rng.integers(0, 2) and variant == 0) else 0.0
     Bn = float(rng.choice([0.03, 0.001]))
     drift = float(rng.choice([0.0, 0.0, 2e-3, -2e-3, 1e-2]))
     X = np.stack([_drifting_burst(rng, N, sps, drift * rng.uniform(0.5, 1.0)) for _ in range(B)])
@@ -144,9 +146,9 @@ def test_fuzz_steady_path(ctx, oracle, trial):
             ("rec", "err", "mu", "dec"), ("rec", "mu", "freq", "dec"), ("err", "sig", "dec")][int(rng.integers(0, 7))]
     ctx.set_option("split", split)
     try:
-        got = dsp_amd.sync_chain_batch(X, sps, alpha, mu0, Bn, 1, scale=scale, outputs=outs, ctx=ctx)
+        got = dsp_amd.sync_chain_batch(X, sps, alpha, mu0, Bn, 1, variant=variant, scale=scale, outputs=outs, ctx=ctx)
     except dsp_amd.DspError as e:
-        assert e.code == -3, e                                  # gardner2.py's own loop does not end on this burst
+        assert e.code == -3 and variant == 0, e                 # gardner2.py's own loop does not end on this burst
         b = int(str(e).split("burst ")[1].split(":")[0])
         with pytest.raises(RuntimeError):
             oracle.gardner_timing_recovery(X[b].astype(np.complex128) * (scale[b] if scale is not None else 1.0), sps, alpha, mu0)
@@ -157,15 +159,21 @@ def test_fuzz_steady_path(ctx, oracle, trial):
     horizon = int(0.9 / (np.pi * 4 * Bn / 1000 / 1.25))
     for b in range(B):
         x = X[b].astype(np.complex128) * (scale[b] if scale is not None else 1.0)
-        rec, err, mu = oracle.gardner_timing_recovery(x, sps, alpha, mu0)
-        n = len(rec)
+        if variant == 0:
+            rec, err, mu = oracle.gardner_timing_recovery(x, sps, alpha, mu0)
+            n, nm = len(rec), len(rec) - 1
+        else:
+            rec, err, mu = oracle.gardner_ted(x, sps, alpha)
+            n = nm = len(rec)
         assert got["n_out"][b] == n, (b, got["n_out"][b], n)
         if "rec" in outs:
             assert np.array_equal(got["rec"][b, :n], rec.astype(cdt)), b
         if "mu" in outs:
-            assert np.array_equal(got["mu"][b, :n - 1], mu.astype(rdt)), b
+            assert np.array_equal(got["mu"][b, :nm], mu.astype(rdt)), b
         if "err" in outs:
-            assert np.array_equal(got["err"][b, :n - 1], err.astype(rdt)), b
+            assert np.array_equal(got["err"][b, :nm], err.astype(rdt)), b
+        if n == 0:
+            continue
         sl, cf, fr, ef = oracle.fll_func(rec, Bn, 1)
         H = min(n, horizon)
         assert np.array_equal(got["dec"][b, :H], oracle.quadrants(sl[:H])), b

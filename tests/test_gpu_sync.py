@@ -334,3 +334,34 @@ def test_large_sps(ctx, oracle, sps):
         sl, cf, fr, ef = oracle.fll_func(rec, 0.03, 1)
         assert np.array_equal(got["dec"][b, :n], oracle.quadrants(sl)), b
         assert np.max(np.abs(got["freq"][b, :n] - fr)) < 1e-12, b
+
+
+@pytest.mark.parametrize("sps,delta", [(2, 0.002), (4, 0.002), (4, 0.05), (6, 0.05), (8, 0.002), (3, 0.002), (4, 0.8)])
+def test_gardner_ted_segments_full_tiles(ctx, oracle, sps, delta):
+    """gardner_ted (hw1/gardner.py:45-72) on full tiles: the speculative segments of the timing wave serve even
+    samples-per-symbol counts (round 3; sps 2 is hw1's own), odd ones keep the per-symbol code, and a gain of
+    0.8 drives mu into the clip of :69, which a segment's evidence must hand to the per-symbol code.  Two full
+    tiles, a partly filled one and one ragged burst; outputs bit-exact against the oracle, decisions exact and
+    frequency <= 1e-12 inside the FLL's stable horizon."""
+    import dsp_amd
+    from test_gpu_fuzz import _burst
+    rng = np.random.default_rng(1200 + sps)
+    B, nsym = 131, 280
+    N = nsym * sps
+    X = np.stack([_burst(rng, N, sps, 1) for _ in range(B)])
+    lens = np.full(B, N, np.int32)
+    lens[130] = N // 2
+    X[130, lens[130]:] = 0
+    got = dsp_amd.sync_chain_batch(X, sps, delta, 0.0, 0.03, 1, variant=1, lens=lens, outputs="all", ctx=ctx)
+    horizon = int(0.9 / (np.pi * 4 * 0.03 / 1000 / 1.25))
+    for b in range(B):
+        y, err, mu = oracle.gardner_ted(X[b, :lens[b]], sps, delta)
+        n = len(y)
+        assert got["n_out"][b] == n, b
+        assert np.array_equal(got["rec"][b, :n], y), b
+        assert np.array_equal(got["mu"][b, :n], mu), b
+        assert np.array_equal(got["err"][b, :n], err), b
+        sl, cf, fr, ef = oracle.fll_func(y, 0.03, 1)
+        H = min(n, horizon)
+        assert np.array_equal(got["dec"][b, :H], oracle.quadrants(sl[:H])), b
+        assert np.max(np.abs(got["freq"][b, :H] - fr[:H])) < 1e-12, b

@@ -26,7 +26,7 @@ from dsp_amd.pipeline import BurstPipeline                   # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 65536
 ctx = dsp_amd.Context(0)
-pipe = BurstPipeline(ctx, B, 2048, 4)
+pipe = BurstPipeline(ctx, B, 2048, 4, variant=int(os.environ.get("VARIANT", "0")))     # VARIANT=1: gardner_ted
 pipe.generate()
 pipe.matched_filter(free_raw=True)
 nt = pipe.ntiles
