@@ -7,7 +7,7 @@ hard decisions), behind the reference's own Python function signatures.
 Everything numeric runs in libdsp_hip.so (hand-written HIP, see dsp_amd/csrc);
 importing the package does not need a GPU, calling a device function does.
 """
-from ._lib import (Context, DspError, default_context, build, lib, LIB_PATH,  # noqa: F401
+from ._lib import (Context, DspError, default_context, build, lib, LIB_PATH, pinned_empty,  # noqa: F401
                    DSP_C64, DSP_C128, DSP_I16, DSP_GARDNER2, DSP_GARDNER_TED, DSP_FLL_ONLY)
 from .api import (rrc_filter, fll_gains, interpolate_sample, gardner_timing_recovery,  # noqa: F401
                   gardner_ted, fll_func, gardner_batch, fll_batch, sync_chain_batch,
@@ -19,7 +19,7 @@ from .api import (rrc_filter, fll_gains, interpolate_sample, gardner_timing_reco
                   fll_slicer_batch, fll_func_constellation, decide_symbols)
 
 __all__ = [
-    "Context", "DspError", "default_context", "build", "lib",
+    "Context", "DspError", "default_context", "build", "lib", "pinned_empty",
     "rrc_filter", "fll_gains", "interpolate_sample",
     "gardner_timing_recovery", "gardner_ted", "fll_func",
     "gardner_batch", "fll_batch", "sync_chain_batch",

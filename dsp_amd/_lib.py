@@ -113,6 +113,8 @@ def _declare(L):
     L.dsp_malloc.argtypes = [vp, C.c_size_t, pvp]
     L.dsp_free.argtypes = [vp, vp]
     L.dsp_memset.argtypes = [vp, vp, ci, C.c_size_t]
+    L.dsp_host_alloc.argtypes = [C.c_size_t, pvp]
+    L.dsp_host_free.argtypes = [vp]
     L.dsp_h2d.argtypes = [vp, vp, vp, C.c_size_t]
     L.dsp_d2h.argtypes = [vp, vp, vp, C.c_size_t]
     L.dsp_stream_copy_dev.argtypes = [vp, vp, vp, C.c_size_t]
@@ -168,7 +170,8 @@ def _declare(L):
                  "dsp_fir_same_std", "dsp_rx_chain", "dsp_fir_tiles_dev", "dsp_synth_bursts_dev",
                  "dsp_sync_capture_segmented", "dsp_sync_capture_segmented_dev", "dsp_synth_stream_dev", "dsp_lagrange_resample", "dsp_fll_class", "dsp_diff_corr",
                  "dsp_cfo_preamble", "dsp_cfo_fourth_power", "dsp_derotate", "dsp_rx_bursts", "dsp_cfo_derotate_dev", "dsp_rx_front_dev", "dsp_fll_slicer", "dsp_trim",
-                 "dsp_device_info", "dsp_capture_validate", "dsp_fir_tiles_static_dev"):
+                 "dsp_device_info", "dsp_capture_validate", "dsp_fir_tiles_static_dev", "dsp_host_alloc",
+                 "dsp_host_free"):
         getattr(L, name).restype = ci
 
 
@@ -257,6 +260,36 @@ class Context:
         ms = C.c_float()
         check(lib().dsp_timer_stop(self.handle, C.byref(ms)))
         return float(ms.value)
+
+
+class _PinnedBlock:
+    """Owner of one dsp_host_alloc block; numpy arrays made by pinned_empty keep it alive through .base."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        self._p = C.c_void_p()
+        check(lib().dsp_host_alloc(self.nbytes, C.byref(self._p)))
+        buf = (C.c_char * max(self.nbytes, 1)).from_address(self._p.value)
+        buf._owner = self                      # the ctypes view keeps the block, numpy keeps the view
+        self.view = buf
+
+    def __del__(self):
+        try:
+            if self._p:
+                lib().dsp_host_free(self._p)
+                self._p = C.c_void_p()
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype):
+    """numpy array in page-locked host memory (dsp_host_alloc): handed to a host-pointer entry point it
+    goes over the link directly at the link's full rate; contents undefined, freed with its last view."""
+    import numpy as np
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape, dtype=np.int64)) if np.ndim(shape) else int(shape)
+    blk = _PinnedBlock(n * dt.itemsize)
+    return np.frombuffer(blk.view, dtype=dt, count=n).reshape(shape)
 
 
 _default_ctx = None

@@ -11,6 +11,7 @@
 #include <atomic>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 struct dsp_ctx {
@@ -46,6 +47,12 @@ struct dsp_ctx {
     size_t scratch_bytes[8];
     void *pinned;       // page-locked host block for the small results a call brings home (seg_info, counts)
     size_t pinned_bytes;
+    // host link (link_h2d / link_d2h): page-locked ring that large transfers from / to the caller's pageable
+    // arrays are staged through by `link_threads` host threads while the previous slot is on the link
+    char *link_ring;
+    hipEvent_t link_ev[4];
+    bool link_busy[4];
+    int link_threads;   // 0 = plain hipMemcpyAsync (the runtime's own staging), default 4
 #ifdef DSP_TRACE
     unsigned long long *trace;
     int trace_stamps;
@@ -94,8 +101,9 @@ static int fail(int code, const char *fmt, ...)
 // driver: a single-burst call makes ~20 of them, and hipMalloc + hipFree (which waits for the device)
 // cost it about a millisecond.  A block is handed out again only after the call that used it has
 // returned, i.e. after that call synchronised its stream (an entry point that fails may return with work
-// in flight: the next release then waits for the device first).  Bounded: 1 GiB and 128 blocks per
-// process, blocks up to 256 MiB; dsp_trim gives everything back.  Contents are undefined, as hipMalloc's.
+// in flight: the next release then waits for the device first).  Bounded: 8 GiB and 128 blocks per
+// process, blocks up to 2 GiB (of 288 GB: a call on 8192 x 8192-sample bursts makes 1.7 GiB of them, and
+// hipMalloc + hipFree of its two 512 MiB blocks cost more than its kernels); dsp_trim gives everything back.  Contents are undefined, as hipMalloc's.
 struct DevCache {
     struct Block { void *p; size_t n; int dev; };
     std::mutex mu;
@@ -141,7 +149,7 @@ struct DevCache {
         }
         {
             std::lock_guard<std::mutex> g(mu);
-            if (n <= ((size_t)256 << 20) && bytes + n <= ((size_t)1 << 30) && free_.size() < 128) {
+            if (n <= ((size_t)2 << 30) && bytes + n <= ((size_t)8 << 30) && free_.size() < 128) {
                 free_.push_back(Block{p, n, dev});
                 bytes += n;
                 return;
@@ -225,6 +233,123 @@ static hipError_t ctx_pinned(dsp_ctx *c, size_t n, void **p)
     return hipSuccess;
 }
 
+// ---------------------------------------------------------------------------
+// The host link.  The host-pointer entry points take the caller's arrays as they are -- numpy arrays in
+// the reference's flows, i.e. pageable memory, which the runtime copies through its own staging buffer
+// at 17-18 GB/s on this pool's boxes (tools/ubench/host_link.hip; page-locked memory: 57 GB/s).  A
+// transfer of LINK_MIN bytes or more is therefore staged here: `link_threads` host threads copy slot k
+// of a page-locked ring while slot k-1 is on the link (52 GB/s either way with four threads).  Arrays
+// that are page-locked already (dsp_host_alloc, hipHostMalloc, hipHostRegister) go over the link directly.
+//   link_h2d: on return the source has been read; the device copy is ordered on the context's stream.
+//   link_d2h: ordered behind the stream's earlier work; a staged transfer is complete on return, a plain
+//             one when the stream has been synchronised (every caller does that before it returns).
+static const size_t LINK_SLOT = (size_t)16 << 20, LINK_MIN = (size_t)4 << 20;
+static const int LINK_SLOTS = 4;
+
+static bool host_is_page_locked(const void *p)
+{
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof(at));
+    hipError_t e = hipPointerGetAttributes(&at, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+
+static void link_par_copy(char *dst, const char *src, size_t n, int T)
+{
+    if (T <= 1 || n < ((size_t)1 << 20)) { memcpy(dst, src, n); return; }
+    const size_t piece = (n / T + 4095) & ~(size_t)4095;
+    std::vector<std::thread> th;
+    th.reserve((size_t)T);
+    size_t own_a = 0, own_b = piece < n ? piece : n;           // the calling thread takes the first piece
+    for (int t = 1; t < T; t++) {
+        const size_t a = (size_t)t * piece, b = a + piece > n ? n : a + piece;
+        if (a >= n) break;
+        try { th.emplace_back([=] { memcpy(dst + a, src + a, b - a); }); }
+        catch (...) { memcpy(dst + a, src + a, b - a); }        // no thread to be had: copy it here
+    }
+    memcpy(dst + own_a, src + own_a, own_b - own_a);
+    for (auto &x : th) x.join();
+}
+
+static hipError_t link_prepare(dsp_ctx *c)
+{
+    if (c->link_ring) return hipSuccess;
+    hipError_t e = hipHostMalloc((void **)&c->link_ring, LINK_SLOT * LINK_SLOTS, hipHostMallocDefault);
+    if (e != hipSuccess) { c->link_ring = nullptr; return e; }
+    for (int i = 0; i < LINK_SLOTS; i++) {
+        if (!c->link_ev[i]) e = hipEventCreateWithFlags(&c->link_ev[i], hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+        c->link_busy[i] = false;
+    }
+    return hipSuccess;
+}
+
+static hipError_t link_slot_wait(dsp_ctx *c, int i)
+{
+    if (!c->link_busy[i]) return hipSuccess;
+    c->link_busy[i] = false;
+    return hipEventSynchronize(c->link_ev[i]);
+}
+
+static hipError_t link_h2d(dsp_ctx *c, void *dst, const void *src, size_t n)
+{
+    if (!n) return hipSuccess;
+    if (n < LINK_MIN || c->link_threads <= 0 || host_is_page_locked(src) || link_prepare(c) != hipSuccess) {
+        (void)hipGetLastError();
+        return hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, c->stream);
+    }
+    int k = 0;
+    for (size_t off = 0; off < n; off += LINK_SLOT, k++) {
+        const size_t m = off + LINK_SLOT > n ? n - off : LINK_SLOT;
+        const int i = k % LINK_SLOTS;
+        char *sl = c->link_ring + (size_t)i * LINK_SLOT;
+        hipError_t e = link_slot_wait(c, i);
+        if (e != hipSuccess) return e;
+        link_par_copy(sl, (const char *)src + off, m, c->link_threads);
+        e = hipMemcpyAsync((char *)dst + off, sl, m, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(c->link_ev[i], c->stream);
+        if (e != hipSuccess) return e;
+        c->link_busy[i] = true;
+    }
+    return hipSuccess;
+}
+
+static hipError_t link_d2h(dsp_ctx *c, void *dst, const void *src, size_t n)
+{
+    if (!n) return hipSuccess;
+    if (n < LINK_MIN || c->link_threads <= 0 || host_is_page_locked(dst) || link_prepare(c) != hipSuccess) {
+        (void)hipGetLastError();
+        return hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, c->stream);
+    }
+    // slot k comes over the link while slot k-1 is copied out to the caller's array
+    int k = 0;
+    size_t prev_off = 0, prev_m = 0;
+    for (size_t off = 0; off < n; off += LINK_SLOT, k++) {
+        const size_t m = off + LINK_SLOT > n ? n - off : LINK_SLOT;
+        const int i = k % LINK_SLOTS;
+        hipError_t e = link_slot_wait(c, i);
+        if (e != hipSuccess) return e;
+        e = hipMemcpyAsync(c->link_ring + (size_t)i * LINK_SLOT, (const char *)src + off, m, hipMemcpyDeviceToHost,
+                           c->stream);
+        if (e == hipSuccess) e = hipEventRecord(c->link_ev[i], c->stream);
+        if (e != hipSuccess) return e;
+        c->link_busy[i] = true;
+        if (k > 0) {
+            const int j = (k - 1) % LINK_SLOTS;
+            e = link_slot_wait(c, j);
+            if (e != hipSuccess) return e;
+            link_par_copy((char *)dst + prev_off, c->link_ring + (size_t)j * LINK_SLOT, prev_m, c->link_threads);
+        }
+        prev_off = off; prev_m = m;
+    }
+    const int j = (k - 1) % LINK_SLOTS;
+    hipError_t e = link_slot_wait(c, j);
+    if (e != hipSuccess) return e;
+    link_par_copy((char *)dst + prev_off, c->link_ring + (size_t)j * LINK_SLOT, prev_m, c->link_threads);
+    return hipSuccess;
+}
+
 static void ctx_trim(dsp_ctx *c)
 {
     for (int i = 0; i < 8; i++) {
@@ -233,6 +358,9 @@ static void ctx_trim(dsp_ctx *c)
     }
     if (c->pinned) (void)hipHostFree(c->pinned);
     c->pinned = nullptr; c->pinned_bytes = 0;
+    for (int i = 0; i < LINK_SLOTS; i++) (void)link_slot_wait(c, i);
+    if (c->link_ring) (void)hipHostFree(c->link_ring);
+    c->link_ring = nullptr;
 }
 
 extern "C" {
@@ -280,6 +408,8 @@ int dsp_create(int device_id, dsp_ctx **out)
     c->trace_stamps = 0;
 #endif
     c->stream = nullptr; c->ev0 = nullptr; c->ev1 = nullptr; c->cu_tickets = nullptr; c->place = nullptr;
+    c->link_ring = nullptr; c->link_threads = 4;
+    for (int i = 0; i < LINK_SLOTS; i++) { c->link_ev[i] = nullptr; c->link_busy[i] = false; }
     hipDeviceProp_t prop;
     hipError_t e = hipGetDeviceProperties(&prop, device_id);
     if (e == hipSuccess) {
@@ -337,6 +467,8 @@ void dsp_destroy(dsp_ctx *c)
     if (c->fir_taps) (void)hipFree(c->fir_taps);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
+    for (int i = 0; i < LINK_SLOTS; i++)
+        if (c->link_ev[i]) (void)hipEventDestroy(c->link_ev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -399,6 +531,9 @@ int dsp_set_option(dsp_ctx *c, const char *name, int64_t value)
     } else if (!strcmp(name, "lead_copy")) {
         if (value < 0 || value > 2) return fail(DSP_E_ARG, "lead_copy must be 0, 1 or 2");
         c->lead_copy = (int)value;
+    } else if (!strcmp(name, "link_threads")) {
+        if (value < 0 || value > 16) return fail(DSP_E_ARG, "link_threads must be in [0,16]");
+        c->link_threads = (int)value;
     } else if (!strcmp(name, "fuse_derot")) {
         c->fuse_derot = value != 0;
     } else if (!strcmp(name, "prio_role")) {
@@ -440,6 +575,22 @@ int dsp_free(dsp_ctx *c, void *dptr)
     if (dptr) HIP_TRY(hipFree(dptr));
     return DSP_OK;
 }
+int dsp_host_alloc(size_t bytes, void **hptr)
+{
+    if (!hptr) return fail(DSP_E_ARG, "hptr is NULL");
+    *hptr = nullptr;
+    hipError_t e = hipHostMalloc(hptr, bytes ? bytes : 16, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(DSP_E_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    }
+    return DSP_OK;
+}
+int dsp_host_free(void *hptr)
+{
+    if (hptr) HIP_TRY(hipHostFree(hptr));
+    return DSP_OK;
+}
 int dsp_memset(dsp_ctx *c, void *dptr, int value, size_t bytes)
 {
     if (!c) return fail(DSP_E_ARG, "ctx is NULL");
@@ -451,7 +602,7 @@ int dsp_h2d(dsp_ctx *c, void *dptr, const void *hptr, size_t bytes)
 {
     if (!c) return fail(DSP_E_ARG, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(link_h2d(c, dptr, hptr, bytes));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DSP_OK;
 }
@@ -459,7 +610,7 @@ int dsp_d2h(dsp_ctx *c, void *hptr, const void *dptr, size_t bytes)
 {
     if (!c) return fail(DSP_E_ARG, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(link_d2h(c, hptr, dptr, bytes));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DSP_OK;
 }
@@ -869,8 +1020,7 @@ static int sync_to_host(dsp_ctx *c, const void *d_xt, int dtype, int64_t B, int6
         if (!o.host) continue;
         HIP_TRY(launch_bursts_from_tiles(o.tiles.p, (int)out_rows, (int)B, d_stage.p, out_stride,
                                          (int)out_stride, o.elem, s));
-        HIP_TRY(hipMemcpyAsync(o.host, d_stage.p, (size_t)B * out_stride * o.elem,
-                               hipMemcpyDeviceToHost, s));
+        HIP_TRY(link_d2h(c, o.host, d_stage.p, (size_t)B * out_stride * o.elem));
         HIP_TRY(hipStreamSynchronize(s));
     }
     std::vector<int32_t> status((size_t)B);
@@ -912,7 +1062,7 @@ static int run_host(dsp_ctx *c, const void *x, int dtype, int64_t B, int64_t N, 
     DevBuf d_x, d_xt, d_lens, d_scale;
     HIP_TRY(d_x.alloc((size_t)B * x_stride * ce));
     HIP_TRY(d_xt.alloc((size_t)ntiles * rows * 64 * ce));
-    HIP_TRY(hipMemcpyAsync(d_x.p, x, (size_t)B * x_stride * ce, hipMemcpyHostToDevice, s));
+    HIP_TRY(link_h2d(c, d_x.p, x, (size_t)B * x_stride * ce));
     if (lens) {
         HIP_TRY(d_lens.alloc((size_t)B * 4));
         HIP_TRY(hipMemcpyAsync(d_lens.p, lens, (size_t)B * 4, hipMemcpyHostToDevice, s));
@@ -1004,9 +1154,9 @@ int dsp_load_iq_i16(dsp_ctx *c, const int16_t *iq, int64_t n_words, int normaliz
     HIP_TRY(d_raw.alloc((size_t)n * 4));
     HIP_TRY(d_out.alloc((size_t)n * 8));
     HIP_TRY(d_tmp.alloc(16));
-    HIP_TRY(hipMemcpyAsync(d_raw.p, iq, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(link_h2d(c, d_raw.p, iq, (size_t)n * 4));
     HIP_TRY(launch_iq_i16(d_raw.p, n, normalize, d_tmp.as<unsigned>(), d_tmp.as<float>() + 1, d_out.p, c->stream));
-    HIP_TRY(hipMemcpyAsync(out_c64, d_out.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(link_d2h(c, out_c64, d_out.p, (size_t)n * 8));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (n_out) *n_out = n;
     return DSP_OK;
@@ -1040,7 +1190,7 @@ static int fir_stage(dsp_ctx *c, FirStage &S, const void *x, int in_kind, int64_
     void *d_src = const_cast<void *>(x);              // bursts already resident (burst cutter) ...
     if (!x_on_device) {                               // ... or uploaded here
         HIP_TRY(S.d_x.alloc((size_t)B * x_stride * ie));
-        HIP_TRY(hipMemcpyAsync(S.d_x.p, x, (size_t)B * x_stride * ie, hipMemcpyHostToDevice, s));
+        HIP_TRY(link_h2d(c, S.d_x.p, x, (size_t)B * x_stride * ie));
         d_src = S.d_x.p;
     }
     if (lens) {
@@ -1227,7 +1377,7 @@ int dsp_fir_same_std(dsp_ctx *c, const void *x, int dtype, int64_t B, int64_t N,
     if (rc != DSP_OK) return rc;
     HIP_TRY(hipMemsetAsync(d_y.p, 0, (size_t)B * y_stride * oe, s));
     HIP_TRY(launch_bursts_from_tiles(S.d_tiles.p, (int)S.rows, (int)B, d_y.p, y_stride, (int)N, oe, s));
-    HIP_TRY(hipMemcpyAsync(y, d_y.p, (size_t)B * y_stride * oe, hipMemcpyDeviceToHost, s));
+    HIP_TRY(link_d2h(c, y, d_y.p, (size_t)B * y_stride * oe));
     if (std_out) HIP_TRY(hipMemcpyAsync(std_out, S.d_std.p, (size_t)B * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return DSP_OK;
@@ -1324,10 +1474,10 @@ int dsp_diff_corr(dsp_ctx *c, const void *x, int dtype, int64_t n, const double 
     DevBuf d_x, d_p, d_c;
     HIP_TRY(d_x.alloc((size_t)n * eb)); HIP_TRY(d_p.alloc((size_t)L * 16));
     HIP_TRY(d_c.alloc((size_t)sps * k_stride * 8));
-    HIP_TRY(hipMemcpyAsync(d_x.p, x, (size_t)n * eb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(link_h2d(c, d_x.p, x, (size_t)n * eb));
     HIP_TRY(hipMemcpyAsync(d_p.p, dpre.data(), (size_t)L * 16, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(launch_diff_corr(d_x.p, dtype == DSP_C128, n, sps, d_p.p, L, d_c.p, k_stride, c->corr_window, c->stream));
-    HIP_TRY(hipMemcpyAsync(conv_c64, d_c.p, (size_t)sps * k_stride * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(link_d2h(c, conv_c64, d_c.p, (size_t)sps * k_stride * 8));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DSP_OK;
 }
@@ -1362,7 +1512,7 @@ int dsp_fll_slicer(dsp_ctx *c, const void *x, int dtype, int64_t B, int64_t N, i
     DevBuf d_x, d_xt, d_lens, d_ff, d_stage, d_pts;
     HIP_TRY(d_x.alloc((size_t)B * x_stride * ce));
     HIP_TRY(d_xt.alloc((size_t)ntiles * rows * 64 * ce));
-    HIP_TRY(hipMemcpyAsync(d_x.p, x, (size_t)B * x_stride * ce, hipMemcpyHostToDevice, s));
+    HIP_TRY(link_h2d(c, d_x.p, x, (size_t)B * x_stride * ce));
     if (lens) {
         HIP_TRY(d_lens.alloc((size_t)B * 4));
         HIP_TRY(hipMemcpyAsync(d_lens.p, lens, (size_t)B * 4, hipMemcpyHostToDevice, s));
@@ -1388,7 +1538,7 @@ int dsp_fll_slicer(dsp_ctx *c, const void *x, int dtype, int64_t B, int64_t N, i
         if (!o.host) continue;
         HIP_TRY(hipMemsetAsync(d_stage.p, 0, (size_t)B * out_stride * o.elem, s));
         HIP_TRY(launch_bursts_from_tiles(o.tiles.p, (int)rows, (int)B, d_stage.p, out_stride, (int)N, o.elem, s));
-        HIP_TRY(hipMemcpyAsync(o.host, d_stage.p, (size_t)B * out_stride * o.elem, hipMemcpyDeviceToHost, s));
+        HIP_TRY(link_d2h(c, o.host, d_stage.p, (size_t)B * out_stride * o.elem));
         HIP_TRY(hipStreamSynchronize(s));
     }
     if (curr_freq) HIP_TRY(hipMemcpyAsync(curr_freq, d_ff.p, (size_t)B * 8, hipMemcpyDeviceToHost, s));
@@ -1424,7 +1574,7 @@ int dsp_cfo_preamble(dsp_ctx *c, const void *x, int dtype, int64_t n, const int6
     DevBuf d_x, d_o, d_p, d_f;
     HIP_TRY(d_x.alloc((size_t)n * eb)); HIP_TRY(d_o.alloc((size_t)B * 8));
     HIP_TRY(d_p.alloc((size_t)n_pre * 16)); HIP_TRY(d_f.alloc((size_t)B * 24));
-    HIP_TRY(hipMemcpyAsync(d_x.p, x, (size_t)n * eb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(link_h2d(c, d_x.p, x, (size_t)n * eb));
     HIP_TRY(hipMemcpyAsync(d_o.p, offsets, (size_t)B * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_p.p, preamble_c128, (size_t)n_pre * 16, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(launch_cfo_preamble(d_x.p, dtype == DSP_C128, d_o.as<int64_t>(), (int)B, sps, d_p.p, n_pre,
@@ -1451,7 +1601,7 @@ int dsp_cfo_fourth_power(dsp_ctx *c, const void *x, int dtype, int64_t B, int64_
     HIP_TRY(hipSetDevice(c->device));
     DevBuf d_x, d_l, d_f;
     HIP_TRY(d_x.alloc((size_t)B * x_stride * eb)); HIP_TRY(d_f.alloc((size_t)B * 8));
-    HIP_TRY(hipMemcpyAsync(d_x.p, x, (size_t)B * x_stride * eb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(link_h2d(c, d_x.p, x, (size_t)B * x_stride * eb));
     if (lens) {
         HIP_TRY(d_l.alloc((size_t)B * 4));
         HIP_TRY(hipMemcpyAsync(d_l.p, lens, (size_t)B * 4, hipMemcpyHostToDevice, c->stream));
@@ -1484,7 +1634,7 @@ int dsp_derotate(dsp_ctx *c, const void *x, int dtype, int64_t n, const int64_t 
     DevBuf d_x, d_o, d_i, d_f, d_y;
     HIP_TRY(d_x.alloc((size_t)n * eb)); HIP_TRY(d_f.alloc((size_t)B * 8));
     HIP_TRY(d_y.alloc((size_t)B * out_stride * 16));
-    HIP_TRY(hipMemcpyAsync(d_x.p, x, (size_t)n * eb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(link_h2d(c, d_x.p, x, (size_t)n * eb));
     HIP_TRY(hipMemcpyAsync(d_f.p, f_rel, (size_t)B * 8, hipMemcpyHostToDevice, c->stream));
     if (offsets) {
         HIP_TRY(d_o.alloc((size_t)B * 8));
@@ -1497,7 +1647,7 @@ int dsp_derotate(dsp_ctx *c, const void *x, int dtype, int64_t n, const int64_t 
     if (out_stride > n_cut) HIP_TRY(hipMemsetAsync(d_y.p, 0, (size_t)B * out_stride * 16, c->stream));
     HIP_TRY(launch_derotate_cut(d_x.p, dtype == DSP_C128, d_o.as<int64_t>(), d_i.as<int64_t>(), d_f.as<double>(), 1,
                                 (int)B, n_cut, d_y.p, out_stride, c->stream));
-    HIP_TRY(hipMemcpyAsync(out_c128, d_y.p, (size_t)B * out_stride * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(link_d2h(c, out_c128, d_y.p, (size_t)B * out_stride * 16));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DSP_OK;
 }
@@ -1562,7 +1712,7 @@ int dsp_rx_bursts(dsp_ctx *c, const void *x, int dtype, int64_t n, const int64_t
     hipStream_t s = c->stream;
     DevBuf d_x, d_o, d_p, d_f, d_cut;
     HIP_TRY(d_x.alloc((size_t)n * eb)); HIP_TRY(d_o.alloc((size_t)B * 8)); HIP_TRY(d_f.alloc((size_t)B * 24));
-    HIP_TRY(hipMemcpyAsync(d_x.p, x, (size_t)n * eb, hipMemcpyHostToDevice, s));
+    HIP_TRY(link_h2d(c, d_x.p, x, (size_t)n * eb));
     HIP_TRY(hipMemcpyAsync(d_o.p, offsets, (size_t)B * 8, hipMemcpyHostToDevice, s));
     if (cfo_method == 0) {
         HIP_TRY(hipMemcpyAsync(d_f.p, f_rel_in, (size_t)B * 8, hipMemcpyHostToDevice, s));
@@ -1629,7 +1779,7 @@ int dsp_fll_class(dsp_ctx *c, const void *x, int dtype, int64_t B, int64_t N, in
     DevBuf d_x, d_xt, d_lens, d_ff, d_stage;
     HIP_TRY(d_x.alloc((size_t)B * x_stride * ce));
     HIP_TRY(d_xt.alloc((size_t)ntiles * rows * 64 * ce));
-    HIP_TRY(hipMemcpyAsync(d_x.p, x, (size_t)B * x_stride * ce, hipMemcpyHostToDevice, s));
+    HIP_TRY(link_h2d(c, d_x.p, x, (size_t)B * x_stride * ce));
     if (lens) {
         HIP_TRY(d_lens.alloc((size_t)B * 4));
         HIP_TRY(hipMemcpyAsync(d_lens.p, lens, (size_t)B * 4, hipMemcpyHostToDevice, s));
@@ -1650,7 +1800,7 @@ int dsp_fll_class(dsp_ctx *c, const void *x, int dtype, int64_t B, int64_t N, in
     for (auto &o : outs) {
         if (!o.host) continue;
         HIP_TRY(launch_bursts_from_tiles(o.tiles.p, (int)rows, (int)B, d_stage.p, out_stride, (int)N, o.elem, s));
-        HIP_TRY(hipMemcpyAsync(o.host, d_stage.p, (size_t)B * out_stride * o.elem, hipMemcpyDeviceToHost, s));
+        HIP_TRY(link_d2h(c, o.host, d_stage.p, (size_t)B * out_stride * o.elem));
         HIP_TRY(hipStreamSynchronize(s));
     }
     if (freq_estimate) HIP_TRY(hipMemcpyAsync(freq_estimate, d_ff.p, (size_t)B * 8, hipMemcpyDeviceToHost, s));
@@ -1672,10 +1822,10 @@ int dsp_lagrange_resample(dsp_ctx *c, const void *x, int dtype, int64_t n, const
     HIP_TRY(hipSetDevice(c->device));
     DevBuf d_x, d_p, d_o;
     HIP_TRY(d_x.alloc((size_t)n * eb)); HIP_TRY(d_p.alloc((size_t)P * 8)); HIP_TRY(d_o.alloc((size_t)P * 16));
-    HIP_TRY(hipMemcpyAsync(d_x.p, x, (size_t)n * eb, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(d_p.p, positions, (size_t)P * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(link_h2d(c, d_x.p, x, (size_t)n * eb));
+    HIP_TRY(link_h2d(c, d_p.p, positions, (size_t)P * 8));
     HIP_TRY(launch_lagrange_resample(d_x.p, dtype == DSP_C128, (int)n, d_p.as<double>(), P, half_len, d_o.p, c->stream));
-    HIP_TRY(hipMemcpyAsync(out_c128, d_o.p, (size_t)P * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(link_d2h(c, out_c128, d_o.p, (size_t)P * 16));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DSP_OK;
 }
@@ -1911,7 +2061,7 @@ int dsp_sync_capture_segmented(dsp_ctx *c, const dsp_capture_args *a)
     const size_t ie = a->in_kind == DSP_I16 ? 4 : 8;
     DevBuf d_x, d_h, d_dec, d_mu, d_freq;
     HIP_TRY(d_x.alloc((size_t)a->n_samples * ie));
-    HIP_TRY(hipMemcpyAsync(d_x.p, a->x, (size_t)a->n_samples * ie, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(link_h2d(c, d_x.p, a->x, (size_t)a->n_samples * ie));
     dsp_capture_args d = *a;
     d.x = d_x.p;
     if (a->h) {
@@ -1928,9 +2078,9 @@ int dsp_sync_capture_segmented(dsp_ctx *c, const dsp_capture_args *a)
     int rc = dsp_sync_capture_segmented_dev(c, &d);
     if (a->n_symbols) *a->n_symbols = total;
     if (rc != DSP_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(a->dec, d_dec.p, (size_t)total, hipMemcpyDeviceToHost, c->stream));
-    if (a->mu) HIP_TRY(hipMemcpyAsync(a->mu, d_mu.p, (size_t)total * 4, hipMemcpyDeviceToHost, c->stream));
-    if (a->freq) HIP_TRY(hipMemcpyAsync(a->freq, d_freq.p, (size_t)total * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(link_d2h(c, a->dec, d_dec.p, (size_t)total));
+    if (a->mu) HIP_TRY(link_d2h(c, a->mu, d_mu.p, (size_t)total * 4));
+    if (a->freq) HIP_TRY(link_d2h(c, a->freq, d_freq.p, (size_t)total * 4));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DSP_OK;
 }

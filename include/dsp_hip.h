@@ -72,6 +72,14 @@ int dsp_set_option(dsp_ctx *ctx, const char *name, int64_t value); /* tuning kno
 int dsp_malloc(dsp_ctx *ctx, size_t bytes, void **dptr);
 int dsp_free(dsp_ctx *ctx, void *dptr);
 int dsp_memset(dsp_ctx *ctx, void *dptr, int value, size_t bytes);
+/* Page-locked host memory for the arrays a caller hands to the host-pointer entry points below.  No
+ * counterpart in the reference (its arrays are numpy's).  Those entry points take any host array; a
+ * pageable one of 4 MiB or more is staged through a page-locked ring of the context by
+ * "link_threads" host threads (dsp_set_option, default 4, 0 = the runtime's own pageable copy), an
+ * array from here goes over the link as it is (57 GB/s against 52 staged and 17-18 GB/s for the
+ * runtime's pageable copy on this pool's boxes, tools/ubench/host_link.hip).  Utility.            */
+int dsp_host_alloc(size_t bytes, void **hptr);
+int dsp_host_free(void *hptr);
 int dsp_h2d(dsp_ctx *ctx, void *dptr, const void *hptr, size_t bytes);
 int dsp_d2h(dsp_ctx *ctx, void *hptr, const void *dptr, size_t bytes);
 /* plain float4 streaming copy kernel (asynchronous; bytes rounded down to 16): bench.py times it
