@@ -873,6 +873,7 @@ static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, c
         break;
     }
     P.TQ = 0;
+    P.spec = c->spec;               // (the one-wave kernel's FLL-only block path obeys the same A/B switch)
     if (split) {
         // queue block: as many symbols as the double buffer can hold inside the budget
         const size_t room = (lds + queue_min > budget ? budget_all : budget) - 32;

@@ -855,6 +855,55 @@ __device__ __forceinline__ bool fll_spec_block(const dspm::MathK &MK, const int 
     return true;
 }
 
+// fll_func on its own (the FLL-only form of the one-wave kernel): the T symbols of a DMA block through
+// fll_step_fast straight from the LDS ring -- the FLL wave's fll_spec_block with the ring in place of the
+// hand-off queue (ring rows wrap: one masked address per symbol).  x_io: the sample of row0 on entry, of
+// row0 + n on return.  The caller guarantees that rows row0 + 1 ... row0 + n are inside the ring window and
+// inside every lane's burst, and that the output rows fit 32-bit offsets.  Returns false (state untouched;
+// the caller runs the block through fll_step) when the evidence word says so.
+template <typename IN, bool SC, int MASK>
+__device__ __forceinline__ bool fll_ring_block(const dspm::MathK &MK, const Tile<IN> &tl, const int n, cd &x_io, const int row0,
+                                               const double i0, double &freq, double &integ, const double kp,
+                                               const double ki, const SpecBasesF &sb, const unsigned lane)
+{
+    typedef typename InT<IN>::OS OS;
+    typedef typename InT<IN>::OC OC;
+    typedef GroupStore<OC> GS;
+    double f = freq, g = integ;
+    dspm::FllEvidence ev;
+    dspm::fll_evidence_init(ev);
+    double idx = (double)row0 + i0, idx4 = 4.0 * idx;
+    unsigned off_c = (unsigned)row0 * 64u * (unsigned)sizeof(OC) + lane * (unsigned)sizeof(OC);
+    unsigned off_s = (unsigned)row0 * 64u * (unsigned)sizeof(OS) + lane * (unsigned)sizeof(OS);
+    unsigned off_b = (unsigned)row0 * 64u + lane;
+    const unsigned colb = tl.lds_base + (unsigned)tl.col * (unsigned)sizeof(IN);
+    const unsigned rm = (unsigned)tl.RM;
+    const double scale = tl.scale;
+    unsigned r = (unsigned)row0;
+    cd x = x_io;
+    for (int t = 0; t < n; t++) {
+        r += 1u;
+        const IN vn = lds_ld<IN>(colb + (r & rm) * (64u * (unsigned)sizeof(IN)));   // next symbol's sample
+        const dspm::FllOut o = dspm::fll_step_fast(MK, x.re, x.im, idx, idx4, f, g, kp, ki, ev);
+        const OC sv = {(OS)o.sr, (OS)o.si};
+        if (MASK == 15) GS::c_s_s_b(off_c, sv, sb.sig_t, off_s, (OS)o.freq, sb.freq_t, (OS)o.ef, sb.ef_t, off_b, (unsigned)o.quad, sb.dec_t);
+        else if (MASK == 10) GS::s_b(off_s, (OS)o.freq, sb.freq_t, off_b, (unsigned)o.quad, sb.dec_t);
+        else if (MASK == 8) GS::b(off_b, (unsigned)o.quad, sb.dec_t);
+        else if (MASK != 0) {
+            if (sb.sig_t) sst(sb.sig_t, off_c, sv);
+            if (sb.freq_t) sst(sb.freq_t, off_s, (OS)o.freq);
+            if (sb.ef_t) sst(sb.ef_t, off_s, (OS)o.ef);
+            if (sb.dec_t) sst_b8(sb.dec_t, off_b, (unsigned)o.quad);
+        }
+        idx += 1.0; idx4 += 4.0;
+        off_c += 64u * (unsigned)sizeof(OC); off_s += 64u * (unsigned)sizeof(OS); off_b += 64u;
+        x = widen<IN, SC>(vn, scale);
+    }
+    if (__any(dspm::fll_evidence_bad(ev))) return false;
+    freq = f; integ = g; x_io = x;
+    return true;
+}
+
 // ---------------------------------------------------------------------------
 // The timing loop with a (2H+1)-point Lagrange interpolator (hw1/test_lagrange_resampling.py:34-72) in
 // place of interpolate(): steady-state iteration, straight-line code out of the LDS ring.
@@ -1037,8 +1086,23 @@ __global__ __launch_bounds__(64) void sync_kernel(SyncParams P)
     const int tile = blockIdx.x;
     const int b = tile * 64 + lane;
     const bool lane_ok = b < P.B;
-    const int len = lane_ok ? (P.lens ? P.lens[b] : P.len_all) : 0;
-    const double scale = (lane_ok && P.scale) ? P.scale[b] : 1.0;
+    int len = lane_ok ? (P.lens ? P.lens[b] : P.len_all) : 0;
+    double scale = (lane_ok && P.scale) ? P.scale[b] : 1.0;
+    // fll_func on its own: the padding lanes of a partly filled tile (63 of them when ONE burst is given) run
+    // as clones of the tile's longest burst -- its column, scale and start values -- so that the block path
+    // below, which needs every lane inside its burst, serves such tiles too; a clone reports nothing (its
+    // output columns are padding), as the two-wave kernel's passenger lanes
+    constexpr bool FBLK = VARIANT == DSP_VARIANT_NONE && FLL && !LAGR;
+    bool pass = false;
+    int src = lane;
+    if constexpr (FBLK) {
+        int lmax = len;
+        for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(lmax, d); lmax = o > lmax ? o : lmax; }
+        const int first = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(lane_ok && len == lmax)) - 1);
+        pass = !lane_ok && lmax > 0 && first >= 0;
+        const double sc = __shfl(scale, first < 0 ? 0 : first);
+        if (pass) { len = lmax; src = first; scale = sc; }
+    }
     const int out_rows = P.out_rows, sps = P.sps, T = P.T;
     const int cap_rows = out_rows - 1;   // the last output row is scratch (uniform stores land there)
     const size_t obase = (size_t)tile * out_rows * 64 + lane;
@@ -1046,6 +1110,7 @@ __global__ __launch_bounds__(64) void sync_kernel(SyncParams P)
 
     Tile<IN> tl;
     tile_init(tl, P, smem, tile, lane, scale);
+    tl.col = src;
     if (ring) tl.prologue(sps, T, P.C);
 
     dspm::LagrangeW LW;
@@ -1059,6 +1124,10 @@ __global__ __launch_bounds__(64) void sync_kernel(SyncParams P)
     if (FLL && lane_ok) {
         if (P.fll_in) { freq = P.fll_in[2 * b]; integ = P.fll_in[2 * b + 1]; }
         if (P.i0) i0 = P.i0[b];
+    }
+    if constexpr (FBLK) {
+        const double f_s = __shfl(freq, src), g_s = __shfl(integ, src), i_s = __shfl(i0, src);
+        if (pass) { freq = f_s; integ = g_s; i0 = i_s; gs.active = true; }
     }
     const double kp = P.kp, ki = P.ki;
     dspm::MathK MK;
@@ -1080,10 +1149,41 @@ __global__ __launch_bounds__(64) void sync_kernel(SyncParams P)
     if (VARIANT == DSP_VARIANT_NONE) gs.active = false;
     bool overflow = false;
 
+    // fll_func on its own: whole DMA blocks through fll_ring_block while every lane of the tile is inside
+    // its burst (one vote per block instead of the per-symbol path's per-lane selects and `easy` vote)
+    int min_len = 0, fmask = 0;
+    SpecBasesF fbases = {nullptr, nullptr, nullptr, nullptr};
+    if constexpr (FBLK) {
+        min_len = len;
+        for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(min_len, d); min_len = o < min_len ? o : min_len; }
+        min_len = __builtin_amdgcn_readfirstlane(min_len);
+        if (!ring || P.spec == 0) min_len = 0;               // (no ring, or the A/B switch: per-symbol path only)
+        fmask = (o_sig ? 1 : 0) | (o_freq ? 2 : 0) | (o_ef ? 4 : 0) | (o_dec ? 8 : 0);
+        const size_t tile_el = (size_t)tile * out_rows * 64;
+        fbases = {o_sig ? (const unsigned char *)(o_sig + tile_el) : nullptr,
+                  o_freq ? (const unsigned char *)(o_freq + tile_el) : nullptr,
+                  o_ef ? (const unsigned char *)(o_ef + tile_el) : nullptr,
+                  o_dec ? (const unsigned char *)(o_dec + tile_el) : nullptr};
+    }
+
     int it = 0;
     bool running = true;
     for (int blk = 0; running; blk++) {
         if (ring) tl.advance(blk, sps, T, P.C, P.nwait);
+        if constexpr (FBLK) {
+            // rows it + 1 ... it + T are read (the last one becomes the next block's first sample)
+            if (it + T < min_len && it + 1 >= tl.win_lo && it + T < tl.win_hi && it + T <= cap_rows &&
+                (unsigned long long)(it + T + 1) * 64ull * sizeof(OC) <= 0xffffffffull) {
+                bool blk_done = false;
+                switch (fmask) {
+                    case 15: blk_done = fll_ring_block<IN, SC, 15>(MK, tl, T, rec_prev, it, i0, freq, integ, kp, ki, fbases, (unsigned)lane); break;
+                    case 10: blk_done = fll_ring_block<IN, SC, 10>(MK, tl, T, rec_prev, it, i0, freq, integ, kp, ki, fbases, (unsigned)lane); break;
+                    case 8: blk_done = fll_ring_block<IN, SC, 8>(MK, tl, T, rec_prev, it, i0, freq, integ, kp, ki, fbases, (unsigned)lane); break;
+                    default: blk_done = fll_ring_block<IN, SC, -1>(MK, tl, T, rec_prev, it, i0, freq, integ, kp, ki, fbases, (unsigned)lane); break;
+                }
+                if (blk_done) { it += T; n_rec += T; continue; }
+            }
+        }
         for (int t = 0; t < T; t++, it++) {
             bool more = (VARIANT == DSP_VARIANT_NONE) ? pending : (gs.active || (FLL && pending));
             if (!__any(more)) { running = false; break; }

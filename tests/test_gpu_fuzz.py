@@ -505,7 +505,10 @@ def test_fuzz_lagrange_and_continuation(ctx, oracle, trial):
                           want_state=True, ctx=ctx)
     for b in (0, 12, 15, 63, 64, 69):
         if ml[b] > cut:
-            assert np.array_equal(np.concatenate([a[2][b, :cut], c[2][b, :ml[b] - cut]]), full[2][b, :ml[b]])
+            # (the same decisions; the frequency to the FLL's bar, not to the bit: whole DMA blocks go through the
+            #  restated step fll_step_fast, the symbols around a burst's ends through fll_step, and a split run
+            #  places its blocks elsewhere than the full run -- the two steps agree to ~1e-16, dsp_math.h)
+            assert np.max(np.abs(np.concatenate([a[2][b, :cut], c[2][b, :ml[b] - cut]]) - full[2][b, :ml[b]])) < FREQ_TOL
             assert np.array_equal(np.concatenate([a[4][b, :cut], c[4][b, :ml[b] - cut]]), full[4][b, :ml[b]])
         o = oracle.fll_func(S[b, :ml[b]], 0.02, 1)
         assert np.max(np.abs(full[2][b, :ml[b]] - o[2])) < FREQ_TOL

@@ -308,6 +308,78 @@ def test_fll_blocks_with_axis_and_zero_samples(ctx, oracle, c64):
         assert np.max(np.abs(got["sig"][b, :n] - sl)) < (1e-6 if c64 else 1e-9) * max(1.0, np.abs(sl).max()), b
 
 
+@pytest.mark.parametrize("c64", [True, False])
+@pytest.mark.parametrize("B", [1, 64, 65, 130])
+def test_fll_alone_block_path(ctx, oracle, c64, B):
+    """fll_func on its own (fll_batch -> the one-wave kernel's FLL-only form): whole DMA blocks go through
+    fll_ring_block (fll_step_fast straight from the LDS ring) while every lane is inside its burst, the
+    padding lanes of a partly filled tile run as clones of its longest burst (B = 1: 63 of them), the ends
+    of ragged bursts take the per-symbol step.  Against the oracle: decisions equal, frequency to the FLL's
+    bar, derotated samples; with an index offset and a start state; and the A/B switch (spec = 0: per-symbol
+    step throughout) agrees to the same bars."""
+    import dsp_amd
+    from test_gpu_fuzz import _burst
+    rng = np.random.default_rng(500 + B)
+    M, Bn = 700, 0.02
+    S = np.stack([_burst(rng, M, 1, 1) for _ in range(B)])
+    lens = np.full(B, M, np.int32)
+    if B > 64:
+        lens[64:] = rng.integers(3, M, B - 64)             # the second tile is ragged
+        for b in range(64, B):
+            S[b, lens[b]:] = 0
+    if c64:
+        S = S.astype(np.complex64)
+    kp, ki = dsp_amd.fll_gains(Bn, 1)
+    i0 = rng.integers(0, 50, B).astype(np.float64)
+    st = np.stack([rng.uniform(-1e-3, 1e-3, B), rng.uniform(-1e-4, 1e-4, B)], axis=1)
+    runs = {}
+    for spec in (1, 0):
+        ctx.set_option("spec", spec)
+        try:
+            runs[spec] = (dsp_amd.fll_batch(S, Bn, 1, lens=lens, ctx=ctx),
+                          dsp_amd.fll_batch(S, Bn, 1, lens=lens, i0=i0, state=st, want_state=True, ctx=ctx))
+        finally:
+            ctx.set_option("spec", 1)
+    ftol, stol = (1e-9, 1e-6) if c64 else (FREQ_TOL, SIG_TOL)
+    for spec, (plain, cont) in runs.items():
+        for b in range(B):
+            n = int(lens[b])
+            sl, cf, fr, ef = oracle.fll_func(S[b, :n].astype(np.complex128), Bn, 1)
+            assert np.array_equal(plain[4][b, :n], oracle.quadrants(sl)), (spec, b)
+            assert np.max(np.abs(plain[2][b, :n] - fr)) < ftol, (spec, b)
+            assert np.max(np.abs(plain[0][b, :n] - sl)) < stol * max(1.0, np.abs(sl).max()), (spec, b)
+            assert not plain[0][b, n:].any() and not plain[4][b, n:].any(), (spec, b)    # rows past the end read zero
+    for b in range(B):                                       # offset + start state: the two paths against each other
+        n = int(lens[b])
+        assert np.array_equal(runs[1][1][4][b, :n], runs[0][1][4][b, :n]), b
+        assert np.max(np.abs(runs[1][1][2][b, :n] - runs[0][1][2][b, :n])) < ftol, b
+        assert np.max(np.abs(runs[1][1][5][b] - runs[0][1][5][b])) < ftol, b
+
+
+@pytest.mark.parametrize("c64", [True, False])
+def test_fll_alone_blocks_with_axis_and_zero_samples(ctx, oracle, c64):
+    """The FLL-only block path's evidence word: a real-valued burst (np.sign(0) = 0 while the estimate is 0),
+    an all-zero one and an imaginary-valued one inside a full tile send their blocks through the
+    reference-order step; every lane comes out as the oracle has it."""
+    import dsp_amd
+    from test_gpu_fuzz import _burst
+    rng = np.random.default_rng(78)
+    B, M = 64, 400
+    S = np.stack([_burst(rng, M, 1, 1) for _ in range(B)])
+    S[5] = S[5].real
+    S[9] = 0
+    S[17] = 1j * S[17].imag
+    S[33, 200:] = S[33, 200:].real
+    if c64:
+        S = S.astype(np.complex64)
+    got = dsp_amd.fll_batch(S, 0.03, 1, ctx=ctx)
+    for b in range(B):
+        sl, cf, fr, ef = oracle.fll_func(S[b].astype(np.complex128), 0.03, 1)
+        assert np.array_equal(got[4][b], oracle.quadrants(sl)), b
+        assert np.max(np.abs(got[2][b] - fr)) < (1e-9 if c64 else FREQ_TOL), b
+        assert np.max(np.abs(got[0][b] - sl)) < (1e-6 if c64 else SIG_TOL) * max(1.0, np.abs(sl).max()), b
+
+
 @pytest.mark.parametrize("sps", [10, 12, 16, 25, 64])
 def test_large_sps(ctx, oracle, sps):
     """Samples-per-symbol counts beyond the sweeps' 1 ... 8 (the C-ABI takes up to 1024): the ring plan shrinks
