@@ -827,7 +827,10 @@ static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, c
     // two waves per tile: both loops run, and the interpolator is the reference's linear one or a
     // Lagrange order (half_len 1 ... 8: sync_kernels.hip parts 1-6)
     const bool lagr_built = P.half_len >= 1 && P.half_len <= 8;
-    const bool can_split = fll && a->variant != 2 && (P.half_len == 0 || lagr_built);
+    // ... or the timing loop alone with the linear interpolator: the two-wave kernel without its FLL (the second
+    // wave feeds the ring), sync_kernels.hip part 7; "spec" = 0 keeps the one-wave kernel for A/B runs
+    const bool timing_alone = !fll && a->variant != 2 && P.half_len == 0 && c->spec != 0;
+    const bool can_split = (fll && a->variant != 2 && (P.half_len == 0 || lagr_built)) || timing_alone;
     const int n_store_t = count_nonnull({P.rec, P.terr, P.mu, P.pos});
     const int n_store_f = count_nonnull({P.sig, P.freq, P.ef, P.dec});
     int per_cu = (ntiles + c->n_cu - 1) / c->n_cu;

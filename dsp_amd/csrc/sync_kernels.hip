@@ -25,10 +25,11 @@
 #include "dsp_internal.h"
 #include "sync_lane.h"
 
-// This file is compiled five times (Makefile): part 0 holds every kernel with the reference's linear
+// This file is compiled eight times (Makefile): part 0 holds every kernel with the reference's linear
 // interpolator, the one-wave kernels and the launch logic; parts 1-6 (-DDSP_SYNC_PART=n) only the
 // two-wave kernel with the Lagrange interpolator inside the timing loop (gardner2 / gardner_ted, half_len
-// 1, 2, 4 / 3, 6, 8), so that the sets of instantiations build side by side.
+// 1, 2, 4 / 3, 6, 8 / 5, 7), part 7 the two-wave kernel without its FLL (the timing loop on its own), so
+// that the sets of instantiations build side by side.
 #ifndef DSP_SYNC_PART
 #define DSP_SYNC_PART 0
 #endif
@@ -1279,7 +1280,11 @@ __device__ __forceinline__ unsigned wave_slot()
 #else
 #define DSP_SPECT_DEFAULT true
 #endif
-template <typename IN, int VARIANT, bool SC, int NWV, int H = 0, bool SPECT = DSP_SPECT_DEFAULT>
+// FLLON = false: the timing loop on its own (gardner_timing_recovery / gardner_ted without fll_func behind
+// them).  The second wave keeps its other job -- it issues, awaits and mirrors the ring's LDS-DMA for the
+// timing wave -- and runs no FLL; the timing wave is the one of the fused kernel, speculative segments and
+// all (part 7 of this file instantiates these; the one-wave kernel ran such a call on its per-symbol path).
+template <typename IN, int VARIANT, bool SC, int NWV, int H = 0, bool SPECT = DSP_SPECT_DEFAULT, bool FLLON = true>
 __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void sync_split_kernel(SyncParams P)
 {
     typedef typename InT<IN>::OS OS;
@@ -1590,7 +1595,8 @@ __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void 
         //  block loops, so that no s_waitcnt vmcnt for them ends up inside -- see load_math_consts)
         asm volatile("" : "+v"(freq), "+v"(integ), "+v"(i0));
         const double kp = P.kp, ki = P.ki;
-        const dspm::MathK MK = load_math_consts();
+        dspm::MathK MK;
+        if constexpr (FLLON) MK = load_math_consts();
         OC *o_sig = (OC *)P.sig; OS *o_freq = (OS *)P.freq; OS *o_ef = (OS *)P.ef;
         uint8_t *o_dec = P.dec;
         // dma_fll: this wave feeds the timing wave's ring.  It waits at the hand-over barriers a third of its
@@ -1612,7 +1618,7 @@ __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void 
             tf.issue(sps * 2 * T + P.C);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // B0
         }
-        if (VARIANT == DSP_VARIANT_GARDNER2) {       // recovered[0] = signal[0]
+        if (FLLON && VARIANT == DSP_VARIANT_GARDNER2) {       // recovered[0] = signal[0]
             const bool have = (lane_ok || pass) && len > 0;
             IN v = xt[src];
             cd r0; r0.re = (double)v.x * scale; r0.im = (double)v.y * scale;
@@ -1656,6 +1662,10 @@ __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void 
             DSP_TR(trp, 0);
             const unsigned qa0 = q_lds + (unsigned)(buf * TQ) * 1024u;
             const int qfl = q_more[buf];
+            if constexpr (!FLLON) {                          // the timing loop on its own: this wave only feeds the ring
+                if (!(qfl & 1)) break;
+                continue;
+            }
             const d2v x0 = lds_ld<d2v>(qa0);                 // in flight while the flags decide the path
             const int more = qfl & 1;
             bool blk_done = false;
@@ -1696,7 +1706,7 @@ __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void 
             }
             if (!more) break;
         }
-        if (lane_ok && P.fll_out) { P.fll_out[2 * b] = freq; P.fll_out[2 * b + 1] = integ; }
+        if (FLLON && lane_ok && P.fll_out) { P.fll_out[2 * b] = freq; P.fll_out[2 * b + 1] = integ; }
     }
 #ifdef DSP_TRACE
     if (P.trace) {
@@ -1716,7 +1726,7 @@ __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void 
 #endif
 }
 
-#if DSP_SYNC_PART >= 1
+#if DSP_SYNC_PART >= 1 && DSP_SYNC_PART <= 6
 // The two-wave kernel with the Lagrange interpolator inside the timing loop, one translation unit per
 // (variant, set of orders) so that they build side by side:
 //   part 1  gardner2, half_len 1, 2, 4      part 2  gardner2, half_len 3, 6, 8      part 5  gardner2, half_len 5, 7
@@ -1769,16 +1779,49 @@ static hipError_t launch_split_lagr_t(const SyncParams &P, size_t lds, hipStream
 }
 #endif
 
+#if DSP_SYNC_PART == 7
+// Part 7: the two-wave kernel without its FLL (sync_split_kernel<..., FLLON = false>): linear interpolator,
+// both timing loops, two waves per tile or four with the CU ticket (the three-wave launch, an option kept
+// for A/B runs of the fused kernel, is served by the two-wave one here).
+template <typename IN>
+static hipError_t launch_split_nofll_t(const SyncParams &P, int variant, size_t lds, hipStream_t s)
+{
+    const int ntiles = (P.B + 63) / 64;
+    const bool four = P.spare_wave == 2 && P.cu_tickets;
+    void (*k)(SyncParams);
+#define DSP_NOFLL_PICK(N)                                                                                              \
+    k = variant == DSP_VARIANT_GARDNER2                                                                                \
+            ? (P.scale ? sync_split_kernel<IN, DSP_VARIANT_GARDNER2, true, N, 0, DSP_SPECT_DEFAULT, false>             \
+                       : sync_split_kernel<IN, DSP_VARIANT_GARDNER2, false, N, 0, DSP_SPECT_DEFAULT, false>)           \
+            : (P.scale ? sync_split_kernel<IN, DSP_VARIANT_TED, true, N, 0, DSP_SPECT_DEFAULT, false>                  \
+                       : sync_split_kernel<IN, DSP_VARIANT_TED, false, N, 0, DSP_SPECT_DEFAULT, false>)
+    if (four) { DSP_NOFLL_PICK(4); } else { DSP_NOFLL_PICK(2); }
+#undef DSP_NOFLL_PICK
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, dim3(ntiles), dim3(four ? 256 : 128), lds, s, P);
+    return hipGetLastError();
+}
+#endif
+
 }  // namespace
 
 #define DSP_CAT2(a, b) a##b
 #define DSP_CAT(a, b) DSP_CAT2(a, b)
-#if DSP_SYNC_PART >= 1
+#if DSP_SYNC_PART >= 1 && DSP_SYNC_PART <= 6
 hipError_t DSP_CAT(launch_sync_split_lagr_part, DSP_SYNC_PART)(const SyncParams &P, bool c128, size_t lds, hipStream_t s)
 {
     return c128 ? launch_split_lagr_t<d2v>(P, lds, s) : launch_split_lagr_t<f2v>(P, lds, s);
 }
+#elif DSP_SYNC_PART == 7
+hipError_t launch_sync_split_nofll(const SyncParams &P, bool c128, int variant, size_t lds, hipStream_t s)
+{
+    return c128 ? launch_split_nofll_t<d2v>(P, variant, lds, s) : launch_split_nofll_t<f2v>(P, variant, lds, s);
+}
 #else
+hipError_t launch_sync_split_nofll(const SyncParams &P, bool c128, int variant, size_t lds, hipStream_t s);
 hipError_t launch_sync_split_lagr_part1(const SyncParams &P, bool c128, size_t lds, hipStream_t s);
 hipError_t launch_sync_split_lagr_part2(const SyncParams &P, bool c128, size_t lds, hipStream_t s);
 hipError_t launch_sync_split_lagr_part3(const SyncParams &P, bool c128, size_t lds, hipStream_t s);
@@ -1841,6 +1884,8 @@ static hipError_t launch_in(const SyncParams &P, int variant, bool fll, size_t l
              : set2 ? launch_sync_split_lagr_part4(P, sizeof(IN) == 16, lds, s)
                     : launch_sync_split_lagr_part3(P, sizeof(IN) == 16, lds, s);
     }
+    if (P.TQ > 0 && !fll)  // the timing loop on its own on the two-wave kernel (part 7)
+        return launch_sync_split_nofll(P, sizeof(IN) == 16, variant, lds, s);
     if (P.TQ > 0) {        // two waves per tile (timing wave + FLL wave)
         int ntiles = (P.B + 63) / 64;
         const int nwv = P.spare_wave == 2 && P.cu_tickets ? 4 : P.spare_wave ? 3 : 2;

@@ -309,6 +309,52 @@ def test_fll_blocks_with_axis_and_zero_samples(ctx, oracle, c64):
 
 
 @pytest.mark.parametrize("c64", [True, False])
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("sps", [2, 3, 4, 8])
+def test_gardner_alone_two_wave_path(ctx, oracle, c64, variant, sps):
+    """The timing loops called on their own (gardner_batch: no fll_func behind them) run on the two-wave
+    kernel without its FLL -- the fused kernel's timing wave, speculative segments and all, with the second
+    wave feeding the ring (sync_kernels.hip part 7).  Two full tiles and a ragged third against the oracle,
+    bit for bit; "spec" = 0 (the one-wave kernel's per-symbol path, what such a call ran on before) gives
+    the same bits."""
+    import dsp_amd
+    from test_gpu_fuzz import _burst
+    rng = np.random.default_rng(900 + 10 * sps + variant)
+    nsym, B = 420, 150
+    N = sps * nsym
+    X = np.stack([_burst(rng, N, sps, 1) for _ in range(B)])
+    lens = np.full(B, N, np.int32)
+    lens[128:] = rng.integers(3 * sps, N, B - 128)
+    for b in range(128, B):
+        X[b, lens[b]:] = 0
+    if c64:
+        X = X.astype(np.complex64)
+    alpha, mu0 = (0.05, 0.37) if variant == 0 else (0.004, 0.0)
+    runs = {}
+    for spec in (1, 0):
+        ctx.set_option("spec", spec)
+        try:
+            runs[spec] = dsp_amd.gardner_batch(X, sps, alpha, mu0, variant=variant, lens=lens, ctx=ctx)
+        finally:
+            ctx.set_option("spec", 1)
+    cdt, rdt = (np.complex64, np.float32) if c64 else (np.complex128, np.float64)
+    g_rec, g_err, g_mu, n_out = runs[1]
+    for b in range(B):
+        x = X[b, :lens[b]].astype(np.complex128)
+        if variant == 0:
+            rec, err, mu = oracle.gardner_timing_recovery(x, sps, alpha, mu0)
+        else:
+            rec, err, mu = oracle.gardner_ted(x, sps, alpha)
+        n = len(rec)
+        assert n_out[b] == n, b
+        assert np.array_equal(g_rec[b, :n], rec.astype(cdt)), b
+        assert np.array_equal(g_mu[b, :len(mu)], mu.astype(rdt)), b
+        assert np.array_equal(g_err[b, :len(err)], err.astype(rdt)), b
+    for u, v in zip(runs[1], runs[0]):
+        assert np.array_equal(u, v)
+
+
+@pytest.mark.parametrize("c64", [True, False])
 @pytest.mark.parametrize("B", [1, 64, 65, 130])
 def test_fll_alone_block_path(ctx, oracle, c64, B):
     """fll_func on its own (fll_batch -> the one-wave kernel's FLL-only form): whole DMA blocks go through
