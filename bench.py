@@ -192,6 +192,44 @@ def committed_traffic(B):
     return None
 
 
+def functions_alone(ctx, pipe, B, reps=5):
+    """HIP-event times of dsp_sync_tiles_dev with do_fll = 0 (the timing loop alone) and with variant 2 on the
+    recovered symbols (fll_func alone); same buffers as the fused launch, whose outputs they reproduce."""
+    import ctypes as C
+    import dsp_amd
+    from dsp_amd._lib import SyncArgs, check
+    L = dsp_amd.lib()
+    fused = pipe._sync_args
+
+    def timed(a):
+        for _ in range(2):
+            check(L.dsp_sync_tiles_dev(ctx.handle, C.byref(a)))
+        ctx.synchronize()
+        ctx.timer_start()
+        for _ in range(reps):
+            check(L.dsp_sync_tiles_dev(ctx.handle, C.byref(a)))
+        return ctx.timer_stop() / reps
+
+    g = SyncArgs()
+    C.memmove(C.byref(g), C.byref(fused), C.sizeof(SyncArgs))
+    g.do_fll = 0
+    g.sig = None; g.freq = None; g.ef = None; g.dec = None
+    g_ms = timed(g)
+    f = SyncArgs()
+    C.memmove(C.byref(f), C.byref(fused), C.sizeof(SyncArgs))
+    f.variant = 2; f.x = pipe.d_out["rec"]; f.in_rows = pipe.out_rows; f.N = pipe.n_sym; f.lens = None
+    f.scale = None; f.rec = None; f.err = None; f.mu = None; f.do_fll = 1
+    f_ms = timed(f)
+    check(L.dsp_sync_tiles_dev(ctx.handle, C.byref(fused)))       # leave the fused outputs behind
+    ctx.synchronize()
+    g_bytes, f_bytes = B * N * 12.0, B * N_SYM * 25.0
+    return {"gardner_timing_recovery": {"kernel": "sync_split_kernel<c64,gardner2,no FLL>", "kernel_ms": g_ms,
+                                        "bytes_per_sample": 12.0, "achieved": g_bytes / (g_ms * 1e-3) / 1e9,
+                                        "frac": g_bytes / (g_ms * 1e-3) / HBM_PEAK},
+            "fll_func": {"kernel": "sync_kernel<c64,fll only>", "kernel_ms": f_ms, "bytes_per_symbol": 25.0,
+                         "achieved": f_bytes / (f_ms * 1e-3) / 1e9, "frac": f_bytes / (f_ms * 1e-3) / HBM_PEAK}}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -203,6 +241,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-other-mode", action="store_true", help="N > 1: do not also time the other scaling mode")
     ap.add_argument("--fir-reps", type=int, default=10, help="timed matched-filter passes for roofline.chain")
+    ap.add_argument("--no-parts", action="store_true", help="skip the timing of the two functions on their own")
     ap.add_argument("--no-capture", action="store_true",
                     help="skip the informational capture-mode record (config.capture_2p30: one 2^30-sample int16 "
                          "capture through the segment-parallel receiver, timed after everything else on rank 0)")
@@ -420,6 +459,11 @@ def rank_main(args):
                      {"kernel_ms": lean_ms, "bytes_per_sample": 8.25,
                       "achieved": B * N * 8.25 / (lean_ms * 1e-3) / 1e9}},
     }
+    # ---- informational: the reference's two functions called on their own, on the same resident bursts
+    #      (gardner_timing_recovery: 8 B read per sample + rec, err, mu = 16 B per symbol -> 12 B/sample;
+    #      fll_func on the recovered symbols: 8 B read + sig, freq, ef, dec = 17 B written per symbol)
+    if rank == 0 and world == 1 and not args.no_parts:
+        line["roofline"]["functions_alone"] = functions_alone(ctx, pipe, B)
     if rank == 0:
         if not args.no_cpu:
             # N > 1: a 3-second sample (the other ranks wait at the closing barrier meanwhile)
