@@ -1305,8 +1305,9 @@ __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void 
     const int b = tile * 64 + lane;
     const bool lane_ok = b < P.B;
     int len = lane_ok ? (P.lens ? P.lens[b] : P.len_all) : 0;
-    // Passenger lanes (gardner2 variant).  The steady path needs every lane of the wave active, so one
-    // idle lane -- the padding lanes of a partly filled last tile, or an empty window of the capture
+    // Passenger lanes (both timing loops; gardner_ted since the end of round 3: ONE burst through
+    // hw1/gardner.py's loop, the drop-in call, stayed on the per-lane path for its 63 idle lanes).
+    // The steady path needs every lane of the wave active, so one idle lane -- the padding lanes of a partly filled last tile, or an empty window of the capture
     // mode -- would keep its whole tile on the slower per-lane path and make that tile the launch's
     // straggler.  Such a lane runs as a CLONE of the tile's longest burst (same column, scale and start
     // values, so it does whatever that burst does and never holds the wave up) and nothing it computes
@@ -1315,7 +1316,7 @@ __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void 
     bool pass = false;
     int src = lane;                                                      // the lane a passenger copies
     double scale = (lane_ok && P.scale) ? P.scale[b] : 1.0;
-    if (VARIANT == DSP_VARIANT_GARDNER2) {
+    if (VARIANT == DSP_VARIANT_GARDNER2 || VARIANT == DSP_VARIANT_TED) {
         int lmax = len;
         for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(lmax, d); lmax = o > lmax ? o : lmax; }
         pass = (!lane_ok || (P.idle_pass && len == 0)) && lmax > 0;
@@ -1406,7 +1407,7 @@ __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void 
         TimingConst tc;
         dspm::GState gs;
         timing_init(tc, gs, P, VARIANT, len, lane_ok, b);
-        if (VARIANT == DSP_VARIANT_GARDNER2) {
+        if (VARIANT == DSP_VARIANT_GARDNER2 || VARIANT == DSP_VARIANT_TED) {
             const double mu_src = __shfl(gs.mu, src);
             if (pass) { gs.active = true; gs.mu = mu_src; tl.col = src; }
         }
@@ -1587,7 +1588,7 @@ __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void 
             if (P.fll_in) { freq = P.fll_in[2 * b]; integ = P.fll_in[2 * b + 1]; }
             if (P.i0) i0 = P.i0[b];
         }
-        if (VARIANT == DSP_VARIANT_GARDNER2) {                           // a passenger starts where its model starts
+        if (VARIANT == DSP_VARIANT_GARDNER2 || VARIANT == DSP_VARIANT_TED) {                           // a passenger starts where its model starts
             const double f_s = __shfl(freq, src), g_s = __shfl(integ, src), i_s = __shfl(i0, src);
             if (pass) { freq = f_s; integ = g_s; i0 = i_s; }
         }
