@@ -31,6 +31,7 @@ struct dsp_ctx {
     int prio_role;      // split kernel: timing waves above FLL waves (1), rotation / none (0), -1 = automatic
     int dma_fll;        // split kernel: the FLL wave issues the ring's DMA (1, default) or the timing wave itself (0)
     int guard;          // split kernel: guard rows behind the LDS ring where they fit (1, default) or never (0)
+    int big_ring;       // split kernel, one tile per CU: ring of up to 128 KiB (1, default) or 64 KiB as in rounds 1-3 (0)
     int spec;           // split kernel, linear interpolator: speculative branch-free segments (1, default) or the per-symbol votes (0)
     int spare_wave;     // split kernel, idle waves for SIMD balance: -1 auto, 0 never, 1 three waves, 2 four waves + CU tickets
     unsigned *cu_tickets;   // [4096] per-CU workgroup counters for the four-wave launch
@@ -395,6 +396,7 @@ int dsp_create(int device_id, dsp_ctx **out)
     c->prio_period = -1;
     c->spare_wave = -1;
     c->spec = 1;
+    c->big_ring = 1;
     c->guard = 1;
     c->dma_fll = 1;
     c->prio_role = -1;
@@ -544,6 +546,8 @@ int dsp_set_option(dsp_ctx *c, const char *name, int64_t value)
         c->guard = value != 0;
     } else if (!strcmp(name, "spec")) {
         c->spec = value != 0;
+    } else if (!strcmp(name, "big_ring")) {
+        c->big_ring = value != 0;
     } else if (!strcmp(name, "spare_wave")) {
         if (value < -1 || value > 2) return fail(DSP_E_ARG, "spare_wave must be -1 (auto), 0, 1 or 2");
         c->spare_wave = (int)value;
@@ -846,13 +850,20 @@ static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, c
         if (budget_all < least) budget_all = least;
         if (budget_all > c->lds_per_cu) budget_all = c->lds_per_cu;
     }
-    // the input ring must stay below 64 KiB (the LDS-DMA base register M0 addresses no more); the
-    // two-wave kernel's hand-off queue may lie above it when the workgroup may have more LDS
+    // the input ring stays below 64 KiB where tiles share a CU (rounds 1-3 took that for M0's reach; it is
+    // not, see ring_cap below); the two-wave kernel's hand-off queue may lie above it
     const size_t budget = budget_all > 64 * 1024 ? 64 * 1024 : budget_all;
     size_t lds = 0;
     bool split = can_split && c->split != 0;
     for (;;) {
         const int n_store = split ? n_store_t : n_store_t + n_store_f;
+        // The LDS-DMA's destination base (M0) reaches the whole LDS of a workgroup, not 64 KiB of it
+        // (tools/ubench/lds_dma_range.hip: a piece sent to base + 162 816 lands there), so where a two-wave tile has
+        // the CU's LDS to itself the ring may take 128 KiB: 128 rows of complex128 -- 11 to 14 symbols per DMA
+        // block instead of 6, as the complex64 ring has always had (complex64 at 64 rows: 1.00 ms against 0.82)
+        const size_t ring_cap = (split && c->big_ring != 0 &&
+                                 budget_all >= (size_t)(128 + 8) * 1024 + (size_t)2 * 7 * 64 * 17 + 64)
+                                    ? (size_t)128 * 1024 : (size_t)64 * 1024;
         int R = c->ring_rows;
         if (R == 0) {
             // 128 rows (8 symbols per DMA block instead of 6: 2 % at up to two tiles per CU) wherever the
@@ -862,12 +873,12 @@ static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, c
             // (the ring alone has to stay inside the 64 KiB the LDS-DMA reaches; ring + queue inside the
             //  tile's share -- a complex128 ring of 64 rows fills the 64 KiB and its queue lies above it:
             //  a single complex128 burst ran 14 % slower on the 32-row ring this loop used to fall to)
-            while (R > 32 && ((size_t)R * 64 * elem > 64 * 1024 ||
+            while (R > 32 && ((size_t)R * 64 * elem > ring_cap ||
                               (size_t)R * 64 * elem + (split ? 2200 : 0) > budget_all) &&
                    sync_plan(elem, sps, P.half_len, a->variant, n_store, R / 2).use_ring)
                 R /= 2;
         }
-        if ((size_t)R * 64 * elem > 64 * 1024) R = 64 * 1024 / (64 * elem);
+        if ((size_t)R * 64 * elem > ring_cap) R = (int)(ring_cap / (64 * elem));
         SyncPlan pl = sync_plan(elem, sps, P.half_len, a->variant, n_store, R);
         // a ring that leaves no room for the smallest queue runs as one wave per tile instead
         if (split && (size_t)pl.lds_bytes + queue_min > budget_all) { split = false; continue; }

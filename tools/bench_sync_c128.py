@@ -3,7 +3,7 @@
 float64 outputs, 32.25 B per sample): the matched-filtered complex64 tiles of the bench workload widened
 on the host and copied back.
 
-    python tools/bench_sync_c128.py [log2_bursts=14]
+    python tools/bench_sync_c128.py [log2_bursts=14] [option=value ...]
 """
 import ctypes as C
 import os
@@ -21,6 +21,9 @@ def main():
     lb = int(sys.argv[1]) if len(sys.argv) > 1 else 14
     B = 1 << lb
     ctx = dsp_amd.Context(0)
+    for opt in sys.argv[2:]:                                  # dsp_set_option names, e.g. big_ring=0
+        k, v = opt.split("=")
+        ctx.set_option(k, int(v))
     L = dsp_amd.lib()
     nb = min(B, 4096)
     pipe = BurstPipeline(ctx, nb, 2048, 4, outputs=("dec",))
