@@ -549,7 +549,7 @@ int dsp_set_option(dsp_ctx *c, const char *name, int64_t value)
     } else if (!strcmp(name, "big_ring")) {
         c->big_ring = value != 0;
     } else if (!strcmp(name, "spare_wave")) {
-        if (value < -1 || value > 2) return fail(DSP_E_ARG, "spare_wave must be -1 (auto), 0, 1 or 2");
+        if (value < -1 || value > 3) return fail(DSP_E_ARG, "spare_wave must be -1 (auto), 0, 1, 2 or 3");
         c->spare_wave = (int)value;
     } else if (!strcmp(name, "prio_period")) {
         if (value != -1 && (value < 0 || value > 4096 || (value & (value - 1))))
@@ -941,7 +941,11 @@ static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, c
         // two 2-wave workgroups per CU land on three SIMDs (sync_kernels.hip); the idle middle wave
         // spreads them over four.  Measured: 512 tiles 1.57 -> 1.30 ms; no gain at one workgroup per
         // CU, 3 % slower at three or four, and at eight the spare waves cost occupancy
-        P.spare_wave = c->spare_wave >= 0 ? c->spare_wave : (per_cu == 2 ? 2 : 0);
+        // At most one tile per CU: a third LIVE wave that feeds the ring in the FLL wave's place (sync_kernels.hip
+        // part 8; the FLL wave is the longer chain there, and a symbol of complex128 at 4 sps is 4 KiB of DMA to issue)
+        const bool feeder_ok = fll && a->variant != 2 && P.half_len == 0 && P.dma_fll != 0;
+        P.spare_wave = c->spare_wave >= 0 ? c->spare_wave : (per_cu == 2 ? 2 : (per_cu == 1 && feeder_ok ? 3 : 0));
+        if (P.spare_wave == 3 && !feeder_ok) P.spare_wave = 0;
         P.cu_tickets = c->cu_tickets;
         P.place = c->place;
         P.spec = c->spec;

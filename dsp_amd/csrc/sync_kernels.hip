@@ -25,11 +25,12 @@
 #include "dsp_internal.h"
 #include "sync_lane.h"
 
-// This file is compiled eight times (Makefile): part 0 holds every kernel with the reference's linear
+// This file is compiled nine times (Makefile): part 0 holds every kernel with the reference's linear
 // interpolator, the one-wave kernels and the launch logic; parts 1-6 (-DDSP_SYNC_PART=n) only the
 // two-wave kernel with the Lagrange interpolator inside the timing loop (gardner2 / gardner_ted, half_len
-// 1, 2, 4 / 3, 6, 8 / 5, 7), part 7 the two-wave kernel without its FLL (the timing loop on its own), so
-// that the sets of instantiations build side by side.
+// 1, 2, 4 / 3, 6, 8 / 5, 7), part 7 the two-wave kernel without its FLL (the timing loop on its own), part 8
+// the fused kernel with a third live wave that feeds the ring, so that the sets of instantiations build
+// side by side.
 #ifndef DSP_SYNC_PART
 #define DSP_SYNC_PART 0
 #endif
@@ -1284,7 +1285,13 @@ __device__ __forceinline__ unsigned wave_slot()
 // them).  The second wave keeps its other job -- it issues, awaits and mirrors the ring's LDS-DMA for the
 // timing wave -- and runs no FLL; the timing wave is the one of the fused kernel, speculative segments and
 // all (part 7 of this file instantiates these; the one-wave kernel ran such a call on its per-symbol path).
-template <typename IN, int VARIANT, bool SC, int NWV, int H = 0, bool SPECT = DSP_SPECT_DEFAULT, bool FLLON = true>
+// DMAW = true (with NWV = 3; part 8): three LIVE waves per tile -- timing, FLL, and a third that does nothing
+// but feed the ring (what the FLL wave does beside its own chain in the two-wave launch: ~70 cycles per KiB
+// issued, 4 KiB per symbol of complex128 at 4 sps).  For launches of at most one tile per CU, where the
+// dispatcher puts the three waves on three SIMDs and the per-symbol latency of the slower chain is the
+// launch's time.  The third wave takes part in every barrier of the FLL wave's schedule.
+template <typename IN, int VARIANT, bool SC, int NWV, int H = 0, bool SPECT = DSP_SPECT_DEFAULT, bool FLLON = true,
+          bool DMAW = false>
 __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void sync_split_kernel(SyncParams P)
 {
     typedef typename InT<IN>::OS OS;
@@ -1299,8 +1306,8 @@ __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void 
     // in between the live waves land on (0,1) and (2,3).  A wave that has ended counts as arrived
     // at every later s_barrier of its workgroup.
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (NWV == 3 && wv == 1) return;
-    int role = wv ? 1 : 0;                                               // 0 = timing, 1 = FLL
+    if (NWV == 3 && !DMAW && wv == 1) return;
+    int role = DMAW ? wv : (wv ? 1 : 0);                                 // 0 = timing, 1 = FLL, 2 = ring feeder (DMAW)
     const int tile = blockIdx.x;
     const int b = tile * 64 + lane;
     const bool lane_ok = b < P.B;
@@ -1596,8 +1603,10 @@ __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void 
         //  block loops, so that no s_waitcnt vmcnt for them ends up inside -- see load_math_consts)
         asm volatile("" : "+v"(freq), "+v"(integ), "+v"(i0));
         const double kp = P.kp, ki = P.ki;
+        // (DMAW: role 1 runs the FLL and feeds nothing, role 2 feeds the ring and runs no FLL; wave-uniform)
+        const bool compute = FLLON && (!DMAW || role == 1);
         dspm::MathK MK;
-        if constexpr (FLLON) MK = load_math_consts();
+        if constexpr (FLLON) { if (compute) MK = load_math_consts(); }
         OC *o_sig = (OC *)P.sig; OS *o_freq = (OS *)P.freq; OS *o_ef = (OS *)P.ef;
         uint8_t *o_dec = P.dec;
         // dma_fll: this wave feeds the timing wave's ring.  It waits at the hand-over barriers a third of its
@@ -1608,18 +1617,19 @@ __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void 
         // block b, and the rows of block b + 2 are issued right AFTER it -- the moments at which the timing
         // wave did both itself.  B0 hands over block 0.
         const bool dma_fll = ring && P.dma_fll != 0;
+        const bool feeder = dma_fll && (!DMAW || role == 2);          // this wave feeds the ring
         const int n_fst = (o_sig ? 1 : 0) + (o_freq ? 1 : 0) + (o_ef ? 1 : 0) + (o_dec ? 1 : 0);
         const int kq = T / TQ;
         Tile<IN> tf;
         int landed = 0, nst = 0;
-        if (dma_fll) {
+        if (feeder) {
             tile_init(tf, P, smem, tile, lane, 1.0);
             tf.prologue(sps, T, P.C);
             landed = tf.F;
             tf.issue(sps * 2 * T + P.C);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // B0
         }
-        if (FLLON && VARIANT == DSP_VARIANT_GARDNER2) {       // recovered[0] = signal[0]
+        if (dma_fll) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // B0
+        if (compute && VARIANT == DSP_VARIANT_GARDNER2) {       // recovered[0] = signal[0]
             const bool have = (lane_ok || pass) && len > 0;
             IN v = xt[src];
             cd r0; r0.re = (double)v.x * scale; r0.im = (double)v.y * scale;
@@ -1646,7 +1656,7 @@ __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void 
             if (prio_n && --prio_c == 0) { prio_c = prio_n; rotate_priority(slot, ++prio_ph); }
             DSP_TR(trp, 5);
             DSP_TT(tt_d);
-            const bool dma_edge = dma_fll && (qb + 1) % kq == 0;    // this barrier ends a block of the timing loop
+            const bool dma_edge = feeder && (qb + 1) % kq == 0;     // this barrier ends a block of the timing loop
             if (dma_edge) {
                 wait_vmcnt(nst);                                    // every DMA issued so far has landed
                 tf.mirror(landed, tf.F);
@@ -1663,9 +1673,11 @@ __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void 
             DSP_TR(trp, 0);
             const unsigned qa0 = q_lds + (unsigned)(buf * TQ) * 1024u;
             const int qfl = q_more[buf];
-            if constexpr (!FLLON) {                          // the timing loop on its own: this wave only feeds the ring
-                if (!(qfl & 1)) break;
-                continue;
+            if constexpr (!FLLON || DMAW) {                  // a wave that only feeds the ring (the timing loop on its own; DMAW's third wave)
+                if (!compute) {
+                    if (!(qfl & 1)) break;
+                    continue;
+                }
             }
             const d2v x0 = lds_ld<d2v>(qa0);                 // in flight while the flags decide the path
             const int more = qfl & 1;
@@ -1707,10 +1719,10 @@ __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void 
             }
             if (!more) break;
         }
-        if (FLLON && lane_ok && P.fll_out) { P.fll_out[2 * b] = freq; P.fll_out[2 * b + 1] = integ; }
+        if (compute && lane_ok && P.fll_out) { P.fll_out[2 * b] = freq; P.fll_out[2 * b + 1] = integ; }
     }
 #ifdef DSP_TRACE
-    if (P.trace) {
+    if (P.trace && role < 2) {
         const unsigned long long tr_t1 = __builtin_amdgcn_s_memtime();
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
@@ -1780,6 +1792,28 @@ static hipError_t launch_split_lagr_t(const SyncParams &P, size_t lds, hipStream
 }
 #endif
 
+#if DSP_SYNC_PART == 8
+// Part 8: the fused kernel with three live waves per tile (sync_split_kernel<..., DMAW = true>, 192 threads):
+// launches of at most one tile per CU.
+template <typename IN>
+static hipError_t launch_split_dmaw_t(const SyncParams &P, int variant, size_t lds, hipStream_t s)
+{
+    const int ntiles = (P.B + 63) / 64;
+    void (*k)(SyncParams) =
+        variant == DSP_VARIANT_GARDNER2
+            ? (P.scale ? sync_split_kernel<IN, DSP_VARIANT_GARDNER2, true, 3, 0, DSP_SPECT_DEFAULT, true, true>
+                       : sync_split_kernel<IN, DSP_VARIANT_GARDNER2, false, 3, 0, DSP_SPECT_DEFAULT, true, true>)
+            : (P.scale ? sync_split_kernel<IN, DSP_VARIANT_TED, true, 3, 0, DSP_SPECT_DEFAULT, true, true>
+                       : sync_split_kernel<IN, DSP_VARIANT_TED, false, 3, 0, DSP_SPECT_DEFAULT, true, true>);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, dim3(ntiles), dim3(192), lds, s, P);
+    return hipGetLastError();
+}
+#endif
+
 #if DSP_SYNC_PART == 7
 // Part 7: the two-wave kernel without its FLL (sync_split_kernel<..., FLLON = false>): linear interpolator,
 // both timing loops, two waves per tile or four with the CU ticket (the three-wave launch, an option kept
@@ -1821,8 +1855,14 @@ hipError_t launch_sync_split_nofll(const SyncParams &P, bool c128, int variant, 
 {
     return c128 ? launch_split_nofll_t<d2v>(P, variant, lds, s) : launch_split_nofll_t<f2v>(P, variant, lds, s);
 }
+#elif DSP_SYNC_PART == 8
+hipError_t launch_sync_split_dmaw(const SyncParams &P, bool c128, int variant, size_t lds, hipStream_t s)
+{
+    return c128 ? launch_split_dmaw_t<d2v>(P, variant, lds, s) : launch_split_dmaw_t<f2v>(P, variant, lds, s);
+}
 #else
 hipError_t launch_sync_split_nofll(const SyncParams &P, bool c128, int variant, size_t lds, hipStream_t s);
+hipError_t launch_sync_split_dmaw(const SyncParams &P, bool c128, int variant, size_t lds, hipStream_t s);
 hipError_t launch_sync_split_lagr_part1(const SyncParams &P, bool c128, size_t lds, hipStream_t s);
 hipError_t launch_sync_split_lagr_part2(const SyncParams &P, bool c128, size_t lds, hipStream_t s);
 hipError_t launch_sync_split_lagr_part3(const SyncParams &P, bool c128, size_t lds, hipStream_t s);
@@ -1887,6 +1927,8 @@ static hipError_t launch_in(const SyncParams &P, int variant, bool fll, size_t l
     }
     if (P.TQ > 0 && !fll)  // the timing loop on its own on the two-wave kernel (part 7)
         return launch_sync_split_nofll(P, sizeof(IN) == 16, variant, lds, s);
+    if (P.TQ > 0 && P.spare_wave == 3)   // three live waves per tile: timing, FLL, ring feeder (part 8)
+        return launch_sync_split_dmaw(P, sizeof(IN) == 16, variant, lds, s);
     if (P.TQ > 0) {        // two waves per tile (timing wave + FLL wave)
         int ntiles = (P.B + 63) / 64;
         const int nwv = P.spare_wave == 2 && P.cu_tickets ? 4 : P.spare_wave ? 3 : 2;

@@ -172,6 +172,61 @@ def test_spare_wave_launch_bit_identical(ctx, oracle, variant):
     pipe.close()
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("c64", [True, False])
+def test_ring_feeder_wave_launch_bit_identical(ctx, oracle, variant, c64):
+    """At most one tile per CU: the fused kernel is launched with THREE live waves per tile -- timing, FLL and a
+    third that only feeds the LDS ring (spare_wave 3, automatic there).  Same bits as the plain two-wave launch
+    for every burst and output: full tiles, a ragged one and a partly filled one, both timing loops, both sample
+    types (complex128 tiles have the 128 KiB ring there; "big_ring" = 0, the 64 KiB one, gives the same bits
+    too), and oracle parity on sampled bursts."""
+    import dsp_amd
+    from test_gpu_fuzz import _burst
+    rng = np.random.default_rng(4100 + variant)
+    sps, nsym, B = 4, 300, 64 * 3 + 17
+    N = sps * nsym
+    X = np.stack([_burst(rng, N, sps, 1) for _ in range(B)])
+    lens = np.full(B, N, np.int32)
+    lens[128:192] = rng.integers(2 * sps, N, 64)               # third tile ragged, fourth partly filled
+    for b in range(128, 192):
+        X[b, lens[b]:] = 0
+    if c64:
+        X = X.astype(np.complex64)
+    alpha = 0.02 if variant == 0 else 0.004
+    scale = rng.uniform(0.5, 2.0, B)
+    got = {}
+    try:
+        for name, sw, br in (("two", 0, 1), ("feeder", -1, 1), ("feeder_small_ring", 3, 0)):
+            ctx.set_option("spare_wave", sw)
+            ctx.set_option("big_ring", br)
+            got[name] = dsp_amd.sync_chain_batch(X, sps, alpha, 0.0, 0.03, 1, variant=variant, lens=lens, scale=scale,
+                                                 outputs="all", ctx=ctx)
+    finally:
+        ctx.set_option("spare_wave", -1)
+        ctx.set_option("big_ring", 1)
+    for k, v in got["two"].items():
+        assert np.array_equal(v, got["feeder"][k]), k
+    # another ring size moves the block boundaries, and with them the symbols that take the FLL's restated step
+    # (fll_step_fast) and the reference-order one (the blocks around a burst's ends): the timing loop's outputs and
+    # the decisions keep their bits, the FLL's float64 outputs agree to its bar
+    for k, v in got["two"].items():
+        w = got["feeder_small_ring"][k]
+        if k in ("sig", "freq", "ef"):
+            assert np.max(np.abs(v - w)) < 1e-12 * max(1.0, float(np.max(np.abs(v)))), k
+        else:
+            assert np.array_equal(v, w), k
+    if variant == 0:
+        cdt = np.complex64 if c64 else np.complex128
+        for b in (0, 63, 130, 191, B - 1):
+            x = X[b, :lens[b]].astype(np.complex128) * scale[b]
+            rec, err, mu = oracle.gardner_timing_recovery(x, sps, alpha, 0.0)
+            n = len(rec)
+            assert got["feeder"]["n_out"][b] == n
+            assert np.array_equal(got["feeder"]["rec"][b, :n], rec.astype(cdt)), b
+            sl, cf, fr, ef = oracle.fll_func(rec, 0.03, 1)
+            assert np.array_equal(got["feeder"]["dec"][b, :n], oracle.quadrants(sl)), b
+
+
 def test_priority_rotation_bit_identical(ctx):
     """Three tiles per CU and more: the two-wave kernel rotates its waves' priorities (prio_period,
     automatic from there on).  Scheduling only -- every output has the bits of the launch without it."""

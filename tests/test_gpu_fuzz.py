@@ -59,6 +59,9 @@ def test_fuzz_chain(ctx, oracle, trial):
     split = int(rng.choice([-1, 0, 1]))
     outs = "all" if rng.integers(0, 2) else ("dec", "mu", "freq", "rec")
     ctx.set_option("split", split)
+    # every other trial on the plain two-wave launch (the shape the bench runs at four tiles per CU); the others on
+    # the automatic one (three live waves -- timing, FLL, ring feeder -- at up to one tile per CU)
+    ctx.set_option("spare_wave", 0 if trial % 2 else -1)
     try:
         got = dsp_amd.sync_chain_batch(X, sps, alpha, mu0, Bn, 1, variant=variant, lens=lens, scale=scale,
                                        outputs=outs, ctx=ctx)
@@ -73,6 +76,7 @@ def test_fuzz_chain(ctx, oracle, trial):
         return
     finally:
         ctx.set_option("split", -1)
+        ctx.set_option("spare_wave", -1)
     kp = 4 * Bn / 1000 / 1.25
     horizon = int(0.9 / (np.pi * kp))
     for b in list(range(min(B, 6))) + ([B - 1] if B > 6 else []) + ([64] if B > 64 else []):
@@ -145,6 +149,7 @@ def test_fuzz_steady_path(ctx, oracle, trial):
     outs = [("rec", "err", "mu", "sig", "freq", "ef", "dec"), ("dec", "mu", "freq"), ("dec",), ("mu", "dec"),
             ("rec", "err", "mu", "dec"), ("rec", "mu", "freq", "dec"), ("err", "sig", "dec")][int(rng.integers(0, 7))]
     ctx.set_option("split", split)
+    ctx.set_option("spare_wave", 0 if trial % 2 else -1)       # (as in test_fuzz_chain)
     try:
         got = dsp_amd.sync_chain_batch(X, sps, alpha, mu0, Bn, 1, variant=variant, scale=scale, outputs=outs, ctx=ctx)
     except dsp_amd.DspError as e:
@@ -155,6 +160,7 @@ def test_fuzz_steady_path(ctx, oracle, trial):
         return
     finally:
         ctx.set_option("split", -1)
+        ctx.set_option("spare_wave", -1)
     cdt, rdt = (np.complex64, np.float32) if c64 else (np.complex128, np.float64)
     horizon = int(0.9 / (np.pi * 4 * Bn / 1000 / 1.25))
     for b in range(B):
@@ -210,6 +216,7 @@ def test_fuzz_steady_path_lagrange(ctx, oracle, trial):
                                        outputs=("rec", "err", "mu", "dec", "freq"), ctx=ctx)
     finally:
         ctx.set_option("split", -1)
+        ctx.set_option("spare_wave", -1)
     tol = 1e-6 if c64 else 1e-11
     for b in (0, 13, 63, B - 1):
         rec, err, mu = gardner2_lagrange_restated(oracle, Xd[b].astype(np.complex128), sps, alpha, half)
