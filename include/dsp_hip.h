@@ -56,7 +56,12 @@ int dsp_set_option(dsp_ctx *ctx, const char *name, int64_t value); /* tuning kno
    "lds_pad", "split" (-1 auto / 0 one wave per tile / 1 two), "queue_block" (hand-off block, 0 auto),
    "prio_period" (rotate wave priorities every N DMA blocks; -1 auto = 8 from three tiles per CU on, 0 off), "spare_wave" (two-wave kernel
    launched with idle waves so that two workgroups on a CU use four SIMDs: -1 auto = at two workgroups
-   per CU, 0 never, 1 one idle wave, 2 two idle waves chosen by a per-CU ticket), "lead_copy" (segment-parallel mode, a window's warm-up rows: 0 = default: the stream is filtered once
+   per CU, 0 never, 1 one idle wave, 2 two idle waves chosen by a per-CU ticket, 3 three LIVE waves -- timing, FLL and one
+   that only feeds the LDS ring -- automatic at up to one workgroup per CU), "big_ring" (1 = default: a tile that has its CU's
+   LDS to itself may use a ring of up to 128 KiB, i.e. 128 rows of complex128; 0 = 64 KiB at most), "link_threads"
+   (host threads that stage transfers of >= 4 MiB from / to pageable host arrays through the context's page-locked ring,
+   default 4, 0 = the runtime's own pageable copy), "spec" (1 = default: speculative branch-free segments / blocks in
+   the recurrence kernels; 0 = the per-symbol paths, for A/B runs; same Gardner bits, FLL to ~1e-16), "lead_copy" (segment-parallel mode, a window's warm-up rows: 0 = default: the stream is filtered once
    into lane-major segment tiles when it is a whole number of 64-segment tiles, else the warm-up rows are stored
    by the predecessor's filter workgroup; 1 = copied by a kernel after the filter; 2 = filtered again),
    "place_ptr" (diagnostic: a device buffer of 2 x tiles uint32 that the four-wave launch fills with the HW_ID /
