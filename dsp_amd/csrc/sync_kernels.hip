@@ -1370,7 +1370,7 @@ __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void 
         if (wv != first && wv != second) return;
         role = wv == first ? 0 : 1;
         // self-check of the placement (dsp_set_option("place_ptr"), tests/test_gpu_fullsize.py)
-        if (P.place && lane == 0) P.place[tile * 2 + role] = 0x80000000u | ((xcc & 15u) << 16) | (hw & 0xffffu);
+        if (P.place && lane == 0 && role < 2) P.place[tile * 2 + role] = 0x80000000u | ((xcc & 15u) << 16) | (hw & 0xffffu);
     }
     const unsigned slot = wave_slot();
     int prio_n = P.prio_period, prio_c = 1, prio_ph = 0;
