@@ -212,6 +212,11 @@ static hipError_t ctx_scratch(dsp_ctx *c, int slot, size_t n, void **p)
         if (c->scratch[slot]) (void)hipFree(c->scratch[slot]);
         c->scratch[slot] = nullptr; c->scratch_bytes[slot] = 0;
         hipError_t e = hipMalloc(&c->scratch[slot], n);
+        if (e == hipErrorOutOfMemory) {            // the blocks kept for the host-pointer entry points go back first
+            (void)hipGetLastError();
+            g_dev_cache->clear(c->device);
+            e = hipMalloc(&c->scratch[slot], n);
+        }
         if (e != hipSuccess) return e;
         c->scratch_bytes[slot] = n;
     }
@@ -569,6 +574,11 @@ int dsp_malloc(dsp_ctx *c, size_t bytes, void **dptr)
     if (!c || !dptr) return fail(DSP_E_ARG, "ctx/dptr is NULL");
     HIP_TRY(hipSetDevice(c->device));
     hipError_t e = hipMalloc(dptr, bytes ? bytes : 16);
+    if (e == hipErrorOutOfMemory) {                // the blocks kept for the host-pointer entry points go back first
+        (void)hipGetLastError();
+        g_dev_cache->clear(c->device);
+        e = hipMalloc(dptr, bytes ? bytes : 16);
+    }
     if (e != hipSuccess) return fail(DSP_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     return DSP_OK;
 }
