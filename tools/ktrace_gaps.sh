@@ -15,7 +15,7 @@ python3 - $f "$FIRST" <<'PY'
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 starts = [i for i, r in enumerate(rows) if sys.argv[2] in r["Kernel_Name"]]
-i0 = starts[-1]
+i0 = starts[-1] if starts else max(0, len(rows) - 40)
 t0 = int(rows[i0]["Start_Timestamp"]); prev_end = t0
 for r in rows[i0:]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
