@@ -71,6 +71,28 @@ def main():
     res["dsp_sync_chain/page_locked_arrays"] = {"ms": dt * 1e3, "Msamples_per_s": B * N / dt / 1e6,
                                                 "link_GBps": link / dt / 1e9, "n_out0": int(n_out[0])}
     x, rec, sig, err, mu, freq, ef, dec = keep
+    # two contexts on two host threads, half the bursts each: one half's upload runs beside the other's download
+    import threading
+    ctx2 = dsp_amd.Context(0)
+    ctx.set_option("link_threads", 4); ctx2.set_option("link_threads", 4)
+    h = B // 2
+
+    def half(cx, lo, hi):
+        check(L.dsp_sync_chain(cx.handle, _vp(x[lo:hi]), 0, hi - lo, N, N, _vp(lens[lo:hi]), None, SPS, 0.007, 0.0, 0, 0,
+                               0.03, 1.0, _vp(rec[lo:hi]), _vp(err[lo:hi]), _vp(mu[lo:hi]), _vp(sig[lo:hi]),
+                               _vp(freq[lo:hi]), _vp(ef[lo:hi]), _vp(dec[lo:hi]), _vp(n_out[lo:hi]), cap))
+
+    def both():
+        ts = [threading.Thread(target=half, args=(ctx, 0, h)), threading.Thread(target=half, args=(ctx2, h, B))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+
+    dt = timed(both)
+    res["dsp_sync_chain/two_contexts_two_threads"] = {"ms": dt * 1e3, "Msamples_per_s": B * N / dt / 1e6,
+                                                      "link_GBps": link / dt / 1e9, "n_out0": int(n_out[0])}
+    ctx2.close()
     # int16 IQ words in, decisions + mu out: the lean flow of worker.py:299-304 on raw bursts
     xi = np.empty((B, 2 * N), np.int16)
     xi[:, 0::2] = np.clip(x.real * 8000, -32768, 32767).astype(np.int16)
