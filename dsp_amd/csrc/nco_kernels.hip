@@ -111,9 +111,79 @@ __device__ __forceinline__ double abs_np(double a, double b)
     return x * __builtin_sqrt(__builtin_fma(r, r, 1.0));
 }
 
-template <typename IN, typename OS, typename OC>
+// np.argmin(np.abs(points - sample)): the first of the nearest points.  abs_np costs a division and a square
+// root per point; squared distances (four operations) decide all but near-ties: a point whose squared distance
+// exceeds the smallest by more than 1e-12 of it cannot win or tie under abs_np (both are the true distance to a
+// few 1e-16), so only points inside that margin go through abs_np, in index order with the strict < of the
+// reference -- the same index as the full scan, bit for bit.  (NaN samples: every comparison is false, index 0,
+// np.argmin's answer for an all-NaN row.)
+template <int NPF>
+__device__ __forceinline__ int nearest_point(const d2v *pt, int n_points, double sr, double si, bool live)
+{
+    double d2[NPF];
+    double best2 = __builtin_inf();
+    int idx = 0;
+#pragma unroll
+    for (int j = 0; j < NPF; j++) {
+        const double ex = pt[j].x - sr, ey = pt[j].y - si;
+        d2[j] = __builtin_fma(ex, ex, ey * ey);
+        const bool lt = (j < n_points) & (d2[j] < best2);
+        best2 = lt ? d2[j] : best2;
+        idx = lt ? j : idx;
+    }
+    const double lim = best2 * (1.0 + 1e-12);
+    int ncand = 0;
+#pragma unroll
+    for (int j = 0; j < NPF; j++) ncand += ((j < n_points) & (d2[j] <= lim)) ? 1 : 0;
+    // (lanes whose result nobody reads -- padding lanes, lanes past their burst's end: all-zero samples, from which
+    //  every point of a PSK ring is equally far -- do not send the wave through the exact comparison)
+    if (__any(live && ncand > 1)) {
+        if (ncand > 1) {
+            // (unrolled with static indices: a run-time index would send pt[] and d2[] to scratch memory)
+            double best = __builtin_inf();
+#pragma unroll
+            for (int j = 0; j < NPF; j++) {
+                const double dist = abs_np(pt[j].x - sr, pt[j].y - si);          // np.abs(d - sample)
+                const bool lt = (j < n_points) & (d2[j] <= lim) & (dist < best);
+                best = lt ? dist : best;
+                idx = lt ? j : idx;
+            }
+        }
+    }
+    return idx;
+}
+
+__device__ __forceinline__ int nearest_point_lds(const d2v *tab, int n_points, double sr, double si)
+{
+    double best2 = __builtin_inf();
+    int idx = 0;
+    for (int j = 0; j < n_points; j++) {
+        const double ex = tab[j].x - sr, ey = tab[j].y - si;
+        const double d2 = __builtin_fma(ex, ex, ey * ey);
+        const bool lt = d2 < best2;
+        best2 = lt ? d2 : best2;
+        idx = lt ? j : idx;
+    }
+    const double lim = best2 * (1.0 + 1e-12);
+    double best = __builtin_inf();
+    int first = -1;
+    for (int j = 0; j < n_points; j++) {
+        const double ex = tab[j].x - sr, ey = tab[j].y - si;
+        if (!(__builtin_fma(ex, ex, ey * ey) <= lim)) continue;
+        if (first < 0) { first = j; continue; }                                  // a lone candidate needs no abs_np
+        if (best == __builtin_inf()) {
+            best = abs_np(tab[first].x - sr, tab[first].y - si);
+            idx = first;
+        }
+        const double dist = abs_np(ex, ey);
+        if (dist < best) { best = dist; idx = j; }
+    }
+    return idx;
+}
+
+template <typename IN, typename OS, typename OC, int KIND>
 __global__ __launch_bounds__(64) void fll_slicer_kernel(const IN *__restrict__ x, const int *__restrict__ lens,
-                                                        int len_all, int B, int rows, int kind,
+                                                        int len_all, int B, int rows,
                                                         const d2v *__restrict__ points, int n_points, double kp,
                                                         double ki, OC *__restrict__ out, OS *__restrict__ freqs,
                                                         OS *__restrict__ efs, unsigned char *__restrict__ dec,
@@ -123,6 +193,12 @@ __global__ __launch_bounds__(64) void fll_slicer_kernel(const IN *__restrict__ x
     const int lane = threadIdx.x, tile = blockIdx.x, b = tile * 64 + lane;
     if (lane < n_points) tab[lane] = points[lane];
     __syncthreads();
+    // (tables of up to 16 points -- every constellation of the reference -- are held in registers: the search
+    //  below is straight-line code; longer tables are read from LDS point by point)
+    constexpr int NPF = 16;
+    d2v pt[NPF];
+#pragma unroll
+    for (int j = 0; j < NPF; j++) pt[j] = (KIND >= 2 && j < n_points) ? points[j] : d2v{0.0, 0.0};
     const int len = b < B ? (lens ? lens[b] : len_all) : 0;
     int max_len = len;
     for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(max_len, d); max_len = o > max_len ? o : max_len; }
@@ -140,20 +216,17 @@ __global__ __launch_bounds__(64) void fll_slicer_kernel(const IN *__restrict__ x
         const double sr = xr * c + xi * s, si = xi * c - xr * s;                 // :32
         double dr, di;
         int idx;
-        if (kind == 0) {
+        if constexpr (KIND == 0) {
             dr = sr > 0.0 ? 1.0 : (sr < 0.0 ? -1.0 : 0.0); di = 0.0;
             idx = sr > 0.0 ? 0 : (sr < 0.0 ? 1 : 2);
-        } else if (kind == 1) {
+        } else if constexpr (KIND == 1) {
             dr = sr > 0.0 ? K.v[dspm::K_SCL] : (sr < 0.0 ? -K.v[dspm::K_SCL] : 0.0);
             di = si > 0.0 ? K.v[dspm::K_SCL] : (si < 0.0 ? -K.v[dspm::K_SCL] : 0.0);
             idx = (int)(sr < 0.0) + 2 * (int)(si < 0.0);
         } else {
-            double best = __builtin_inf();
-            idx = 0;
-            for (int j = 0; j < n_points; j++) {
-                const double dist = abs_np(tab[j].x - sr, tab[j].y - si);         // np.abs(d - sample)
-                if (dist < best) { best = dist; idx = j; }
-            }
+            if (n_points <= 8) idx = nearest_point<8>(pt, n_points, sr, si, live);
+            else if (n_points <= NPF) idx = nearest_point<NPF>(pt, n_points, sr, si, live);
+            else idx = nearest_point_lds(tab, n_points, sr, si);
             dr = tab[idx].x; di = tab[idx].y;
         }
         const double zr = sr * dr + si * di, zi = si * dr - sr * di;             // sample * conj(decided)
@@ -197,13 +270,20 @@ hipError_t launch_fll_slicer(const void *x, int c128, const int *lens, int len_a
 {
     if (B <= 0) return hipSuccess;
     const int nt = (B + 63) / 64;
-    if (c128)
-        hipLaunchKernelGGL((fll_slicer_kernel<d2v, double, d2v>), dim3(nt), dim3(64), 0, s, (const d2v *)x, lens,
-                           len_all, B, rows, kind, (const d2v *)points, n_points, kp, ki, (d2v *)out, (double *)freqs,
-                           (double *)efs, dec, freq_final);
-    else
-        hipLaunchKernelGGL((fll_slicer_kernel<f2v, float, f2v>), dim3(nt), dim3(64), 0, s, (const f2v *)x, lens,
-                           len_all, B, rows, kind, (const d2v *)points, n_points, kp, ki, (f2v *)out, (float *)freqs,
-                           (float *)efs, dec, freq_final);
+#define DSP_SLICER_LAUNCH(KIND)                                                                                      \
+    do {                                                                                                             \
+        if (c128)                                                                                                    \
+            hipLaunchKernelGGL((fll_slicer_kernel<d2v, double, d2v, KIND>), dim3(nt), dim3(64), 0, s, (const d2v *)x, \
+                               lens, len_all, B, rows, (const d2v *)points, n_points, kp, ki, (d2v *)out,            \
+                               (double *)freqs, (double *)efs, dec, freq_final);                                     \
+        else                                                                                                         \
+            hipLaunchKernelGGL((fll_slicer_kernel<f2v, float, f2v, KIND>), dim3(nt), dim3(64), 0, s, (const f2v *)x,  \
+                               lens, len_all, B, rows, (const d2v *)points, n_points, kp, ki, (f2v *)out,            \
+                               (float *)freqs, (float *)efs, dec, freq_final);                                       \
+    } while (0)
+    if (kind == 0) DSP_SLICER_LAUNCH(0);
+    else if (kind == 1) DSP_SLICER_LAUNCH(1);
+    else DSP_SLICER_LAUNCH(2);
+#undef DSP_SLICER_LAUNCH
     return hipGetLastError();
 }

@@ -86,6 +86,36 @@ def test_fll_slicer_batch_ragged_and_c64():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("c", ["8psk", "16psk", "16apsk"])
+def test_nearest_point_ties_as_numpy(c):
+    """The table slicers decide by squared distances and send only near-ties through numpy's own np.abs
+    expression (nco_kernels.hip: nearest_point).  Samples ON the decision boundaries -- midpoints of every pair
+    of points, the origin (every point of a PSK ring equally far), points themselves, the same scaled and
+    nudged by an ulp or 1e-13 -- must decide as np.argmin(np.abs(points - sample)) does: the first of the
+    nearest in the reference's order, whatever the last bits of the two np.abs values say."""
+    import dsp_amd
+    rng = np.random.default_rng(31)
+    pts = O.constellation_points(c)
+    mids = np.array([(p + q) / 2 for i, p in enumerate(pts) for q in pts[i + 1:]])
+    base = np.concatenate([mids, [0j], pts, 0.5 * mids, 2.0 * mids, rng.standard_normal(64) + 1j * rng.standard_normal(64)])
+    xs = [base]
+    for eps in (1e-16, 1e-15, 1e-13, 1e-11, 1e-9):
+        xs.append(base * (1 + eps))
+        xs.append(base + eps * (rng.standard_normal(base.size) + 1j * rng.standard_normal(base.size)))
+    nz = base[(base.real != 0) & (base.imag != 0)]           # (an ulp off ZERO is a subnormal: outside the loops' range of
+    xs.append(np.nextafter(nz.real, 9.0) + 1j * nz.imag)     #  sample magnitudes, dsp_math.h div_fast)
+    xs.append(nz.real + 1j * np.nextafter(nz.imag, -9.0))
+    x = np.concatenate(xs)
+    want = np.array([np.argmin(np.abs(pts - v)) for v in x], dtype=np.uint8)
+    _, idx = dsp_amd.decide_symbols(x, c)
+    assert np.array_equal(idx, want), np.flatnonzero(idx != want)[:10]
+    # the same samples spread over a full tile (no padding lanes), one burst per lane
+    n = x.size // 64 * 64
+    o = dsp_amd.fll_slicer_batch(x[:n].reshape(64, -1), 0.0, 1, c, outputs=("dec",))
+    assert np.array_equal(o["dec"].reshape(-1), want[:n])
+
+
+@pytest.mark.gpu
 def test_receiver_8psk_end_to_end():
     """worker.Processing.process with a table slicer (8psk) on a seeded worker.Generation signal:
     peaks as the reference found them, FLL outputs as it returned them."""

@@ -21,3 +21,6 @@ ms, r = t(lambda: dsp_amd.fll_func(rec, 0.03, 1))
 print("fll_func", "%.2f ms" % ms, len(rec), "symbols -> %.3f us/symbol" % (ms * 1e3 / len(rec)))
 ms, r = t(lambda: dsp_amd.sync_chain_batch(x[None, :], 4, 0.007, 0.0, 0.03, 1))
 print("sync_chain_batch B=1", "%.2f ms" % ms, "-> %.3f us/symbol" % (ms * 1e3 / nsym))
+for cst in ("bpsk", "8psk", "16apsk"):
+    ms, r = t(lambda: dsp_amd.fll_func_constellation(rec, 0.03, 1, cst))
+    print("fll_func_constellation", cst, "%.2f ms" % ms, "-> %.3f us/symbol" % (ms * 1e3 / len(rec)))
