@@ -193,6 +193,19 @@ template <typename OC> struct GroupStore;
                          :: "v"(oc), "v"(c), "s"(bc), "v"(os), "v"(a), "s"(ba), "v"(b), "s"(bb), "v"(ob), "v"(q), \
                             "s"(bq) : "memory");                                                                  \
         }                                                                                                         \
+        static __device__ __forceinline__ void c_s_b(unsigned oc, OC_T c, const void *bc, unsigned os, OS_T a,   \
+                                                     const void *ba, unsigned ob, unsigned q, const void *bq)    \
+        {                                                                                                         \
+            asm volatile("s_nop 4\n\t" OCOP " %0, %1, %2" DSP_ST_MOD "\n\t" OSOP " %3, %4, %5" DSP_ST_MOD "\n\t"                                   \
+                         "global_store_byte %6, %7, %8" DSP_ST_MOD PAD                                                        \
+                         :: "v"(oc), "v"(c), "s"(bc), "v"(os), "v"(a), "s"(ba), "v"(ob), "v"(q), "s"(bq) : "memory");  \
+        }                                                                                                         \
+        static __device__ __forceinline__ void c_b(unsigned oc, OC_T c, const void *bc, unsigned ob, unsigned q, \
+                                                   const void *bq)                                               \
+        {                                                                                                         \
+            asm volatile("s_nop 4\n\t" OCOP " %0, %1, %2" DSP_ST_MOD "\n\tglobal_store_byte %3, %4, %5" DSP_ST_MOD PAD               \
+                         :: "v"(oc), "v"(c), "s"(bc), "v"(ob), "v"(q), "s"(bq) : "memory");                       \
+        }                                                                                                         \
         static __device__ __forceinline__ void s_b(unsigned os, OS_T a, const void *ba, unsigned ob, unsigned q, \
                                                    const void *bq)                                               \
         {                                                                                                         \
@@ -816,7 +829,8 @@ __device__ __forceinline__ bool ted_spec_segment(const Tile<IN> &tl, dspm::GStat
 // The FLL wave's side of it: a queue block whose symbols all came from speculative segments (every lane
 // produced every symbol) through fll_step_fast, one vote at the end (a derotated sample with a component
 // exactly zero, a quadrant index beyond int32: the caller then runs the block through fll_step from the
-// saved state).  MASK: 1 sig, 2 freq, 4 ef, 8 dec; -1 = decided at run time per store.
+// saved state).  MASK: 1 sig, 2 freq, 4 ef, 8 dec; -1 = decided at run time per store (specialised: all four,
+// sig + freq + dec, sig + dec, freq + dec, dec: the subsets the host layers ask for).
 struct SpecBasesF { const unsigned char *sig_t, *freq_t, *ef_t, *dec_t; };
 
 template <typename OS, typename OC, int MASK>
@@ -840,6 +854,8 @@ __device__ __forceinline__ bool fll_spec_block(const dspm::MathK &MK, const int 
         const dspm::FllOut o = dspm::fll_step_fast(MK, x.x, x.y, idx, idx4, f, g, kp, ki, ev);
         const OC sv = {(OS)o.sr, (OS)o.si};
         if (MASK == 15) GS::c_s_s_b(off_c, sv, sb.sig_t, off_s, (OS)o.freq, sb.freq_t, (OS)o.ef, sb.ef_t, off_b, (unsigned)o.quad, sb.dec_t);
+        else if (MASK == 11) GS::c_s_b(off_c, sv, sb.sig_t, off_s, (OS)o.freq, sb.freq_t, off_b, (unsigned)o.quad, sb.dec_t);
+        else if (MASK == 9) GS::c_b(off_c, sv, sb.sig_t, off_b, (unsigned)o.quad, sb.dec_t);
         else if (MASK == 10) GS::s_b(off_s, (OS)o.freq, sb.freq_t, off_b, (unsigned)o.quad, sb.dec_t);
         else if (MASK == 8) GS::b(off_b, (unsigned)o.quad, sb.dec_t);
         else if (MASK != 0) {
@@ -1687,6 +1703,8 @@ __global__ __launch_bounds__(64 * NWV, (H == 0 ? DSP_SPLIT_MIN_WAVES : 1)) void 
                 const unsigned qa = qa0;
                 switch (fmask) {
                     case 15: blk_done = fll_spec_block<OS, OC, 15>(MK, TQ, qa, x0, it + ROFF, i0, freq, integ, kp, ki, fbases, (unsigned)lane); break;
+                    case 11: blk_done = fll_spec_block<OS, OC, 11>(MK, TQ, qa, x0, it + ROFF, i0, freq, integ, kp, ki, fbases, (unsigned)lane); break;
+                    case 9: blk_done = fll_spec_block<OS, OC, 9>(MK, TQ, qa, x0, it + ROFF, i0, freq, integ, kp, ki, fbases, (unsigned)lane); break;
                     case 10: blk_done = fll_spec_block<OS, OC, 10>(MK, TQ, qa, x0, it + ROFF, i0, freq, integ, kp, ki, fbases, (unsigned)lane); break;
                     case 8: blk_done = fll_spec_block<OS, OC, 8>(MK, TQ, qa, x0, it + ROFF, i0, freq, integ, kp, ki, fbases, (unsigned)lane); break;
                     case 0: blk_done = fll_spec_block<OS, OC, 0>(MK, TQ, qa, x0, it + ROFF, i0, freq, integ, kp, ki, fbases, (unsigned)lane); break;
