@@ -418,8 +418,15 @@ def test_fuzz_capture_with_matched_filter(ctx, oracle, trial):
         ctx.set_option("lead_copy", 0)
     a, b = outs
     assert a["n"] == b["n"] and a["seg_info"].shape[0] == nseg
-    for k in ("dec", "mu", "freq", "seg_info"):
+    for k in ("dec", "seg_info"):
         assert np.array_equal(a[k], b[k]), k
+    # mu and freq: float32 roundings of float64 trajectories that the two filter passes start one ulp apart (the
+    # whole-stream std is merged from differently grouped partial statistics): equal to the bit but for a value
+    # that sits on a rounding boundary -- trial 1149 of the 100 x soak: ONE freq of 132 096, -6.2483022e-12
+    # against -6.248302e-12 where the estimate crosses zero
+    assert np.max(np.abs(a["mu"] - b["mu"]), initial=0) < 1e-6
+    assert np.max(np.abs(a["freq"] - b["freq"]), initial=0) < 1e-10
+    assert np.mean(a["mu"] == b["mu"]) > 0.9999 and np.mean(a["freq"] == b["freq"]) > 0.9999
     yf = oracle.convolve_same(xc, h)
     ref = oracle.sync_capture_segmented(yf.astype(np.complex64), sps, 0.007, 0.0, 0.003, 1.0, seg_len=seg_len,
                                         warmup=warm, scale=1.0 / oracle.np_std(yf), acquire=acquire)
