@@ -420,9 +420,10 @@ def test_fuzz_capture_with_matched_filter(ctx, oracle, trial):
     assert a["n"] == b["n"] and a["seg_info"].shape[0] == nseg
     for k in ("dec", "seg_info"):
         assert np.array_equal(a[k], b[k]), k
-    # mu and freq: float32 roundings of float64 trajectories that the two filter passes start one ulp apart (the
-    # whole-stream std is merged from differently grouped partial statistics): equal to the bit but for a value
-    # that sits on a rounding boundary -- trial 1149 of the 100 x soak: ONE freq of 132 096, -6.2483022e-12
+    # mu and freq: float32 roundings of float64 trajectories that are not the same to the last bit between the two
+    # filter passes (spec = 0 and every launch shape show it alike: not the recurrence kernel; the whole-stream std
+    # is merged from differently grouped partial statistics): equal to the bit but for a value that sits on a
+    # rounding boundary -- trial 1149 of the 100 x soak: ONE freq of 132 096, -6.2483022e-12
     # against -6.248302e-12 where the estimate crosses zero
     assert np.max(np.abs(a["mu"] - b["mu"]), initial=0) < 1e-6
     assert np.max(np.abs(a["freq"] - b["freq"]), initial=0) < 1e-10
