@@ -751,7 +751,13 @@ static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, c
     if (!a->x) return fail(DSP_E_ARG, "sync: x is NULL");
     if (a->dtype != DSP_C64 && a->dtype != DSP_C128) return fail(DSP_E_ARG, "sync: bad dtype");
     if (a->variant < 0 || a->variant > 2) return fail(DSP_E_ARG, "sync: bad variant");
-    const bool fll = a->do_fll != 0 || a->variant == 2;
+    // The timing loop alone with a Lagrange interpolator (do_fll = 0, interp_half_len 1 ... 8): the two-wave Lagrange
+    // kernels exist only with their FLL wave, and the one-wave kernel runs such a call on its per-lane path (5-10 x
+    // slower).  The call therefore goes out on the two-wave kernel with an idle FLL: zero gains, no FLL outputs, no
+    // state in or out -- the timing wave's outputs are those of any other launch of it.
+    const bool lagr_alone = a->do_fll == 0 && a->variant != 2 && a->interp_half_len >= 1 && a->interp_half_len <= 8 &&
+                            c && c->spec != 0 && c->split != 0;
+    const bool fll = a->do_fll != 0 || a->variant == 2 || lagr_alone;
     const int sps = a->variant == 2 ? 1 : a->sps;
     if (sps < 1 || sps > 1024) return fail(DSP_E_ARG, "sync: sps out of range");
     if (a->N < 0 || a->N >= (1LL << 30)) return fail(DSP_E_ARG, "sync: N out of range");
@@ -760,7 +766,7 @@ static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, c
     if (a->out_rows < 2 || a->out_rows >= (1LL << 30)) return fail(DSP_E_ARG, "sync: bad out_rows");
     if (a->interp_half_len < 0 || a->interp_half_len > 8)
         return fail(DSP_E_ARG, "sync: interp_half_len must be in [0,8]");
-    if (fll && !(a->y > 0.0)) return fail(DSP_E_ARG, "sync: y must be > 0");
+    if (fll && !lagr_alone && !(a->y > 0.0)) return fail(DSP_E_ARG, "sync: y must be > 0");
 
     // More tiles than a CU keeps resident (as far as the kernel's registers go, read from the code object --
     // the Lagrange kernels hold up to 281 -- and at most four, see below): the surplus would run as a second, poorly filled
@@ -819,14 +825,15 @@ static int sync_tiles_run(dsp_ctx *c, const dsp_sync_args *a, int x_tile_rows, c
     P.B = (int)a->B; P.in_rows = (int)a->in_rows; P.len_all = (int)a->N; P.sps = sps;
     P.x_tile_rows = x_tile_rows > 0 ? x_tile_rows : P.in_rows; P.x_tile0 = x_tile0; P.idle_pass = idle_pass;
     P.alpha = a->alpha; P.mu0 = a->mu0; P.mu0_per = a->variant == DSP_GARDNER2 ? a->mu0_per : nullptr; P.half_len = a->variant == 2 ? 0 : a->interp_half_len;
-    if (fll) dsp_fll_gains(a->Bn, a->y, &P.kp, &P.ki);
-    P.i0 = a->i0; P.fll_in = a->fll_state_in; P.fll_out = a->fll_state_out;
+    if (fll && !lagr_alone) dsp_fll_gains(a->Bn, a->y, &P.kp, &P.ki);
+    P.i0 = a->i0; P.fll_in = lagr_alone ? nullptr : a->fll_state_in; P.fll_out = lagr_alone ? nullptr : a->fll_state_out;
     P.rec = a->variant == 2 ? nullptr : a->rec;
     P.terr = a->variant == 2 ? nullptr : a->err;
     P.mu = a->variant == 2 ? nullptr : a->mu;
     P.pos = a->variant == 2 ? nullptr : a->pos;
-    P.sig = fll ? a->sig : nullptr; P.freq = fll ? a->freq : nullptr; P.ef = fll ? a->ef : nullptr;
-    P.dec = fll ? a->dec : nullptr;
+    const bool fll_out = fll && !lagr_alone;
+    P.sig = fll_out ? a->sig : nullptr; P.freq = fll_out ? a->freq : nullptr; P.ef = fll_out ? a->ef : nullptr;
+    P.dec = fll_out ? a->dec : nullptr;
     P.out_rows = (int)a->out_rows; P.n_out = a->n_out; P.status = a->status;
 #ifdef DSP_TRACE
     P.trace = c->trace;
