@@ -121,7 +121,11 @@ int dsp_gardner(dsp_ctx *ctx, const void *x, int dtype, int64_t B, int64_t N, in
 /* fll_func(signal, Bn, y) for B independent symbol streams (a6, a7) --
  * fll_func.py:3-29.  M: per-stream symbol counts (NULL = all M_max).
  * i0 / state_in / state_out (NULL = reference behaviour: index 0, zero state)
- * continue a loop at absolute index i0[b] from {curr_freq, integrator}.
+ * continue a loop at absolute index i0[b] from {curr_freq, integrator}.  A continued
+ * run decides as one run over the whole stream does and follows its frequency to the
+ * FLL's bar (1e-12), not to the last bit: whole blocks of symbols go through a restated
+ * form of the step (same values to ~1e-16, dsp_math.h fll_step_fast), the symbols
+ * around a burst's ends through the reference-order one, and a cut moves the blocks.
  * Outputs [B][out_stride]: out = signal_list, freq = curr_freq_list,
  * ef = ef_n_list, dec = quadrant (Re<0) + 2*(Im<0) of signal_list.             */
 int dsp_fll(dsp_ctx *ctx, const void *x, int dtype, int64_t B, const int32_t *M, int64_t M_max,
