@@ -326,7 +326,19 @@ DSP_HD double from_words(unsigned hi, unsigned lo)
     return x;
 }
 // mask ? a : b per bit (mask all ones or all zeros)
-DSP_HD unsigned bsel(unsigned mask, unsigned a, unsigned b) { return (a & mask) | (b & ~mask); }
+DSP_HD unsigned bsel(unsigned mask, unsigned a, unsigned b)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DSP_NO_BFI)      // (-DDSP_NO_BFI: A/B builds, tools/build_ab.sh)
+    // v_bfi_b32 D = (S0 & S1) | (~S0 & S2): ONE instruction; left to itself hipcc emits v_and_b32 + v_and_or_b32
+    // (with ~mask kept in a register) for this expression -- two issue slots per select on a wave that fills its
+    // SIMD's VALU by itself (119-132 instructions per symbol, tools/ubench/issue_latency.hip)
+    unsigned d;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(mask), "v"(a), "v"(b));
+    return d;
+#else
+    return (a & mask) | (b & ~mask);
+#endif
+}
 DSP_HD double bsel64(unsigned mask, double a, double b)
 {
     return from_words(bsel(mask, hi_word(a), hi_word(b)), bsel(mask, lo_word(a), lo_word(b)));

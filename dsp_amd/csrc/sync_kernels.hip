@@ -22,9 +22,6 @@
 //   steady   all lanes active, window clear of the burst ends: one vote, no commit selects;
 //   fast     the same arithmetic committed per lane by select;
 //   generic  per-lane code: mu wrap loops (symbol slips), rows outside the ring from global memory.
-#include "dsp_internal.h"
-#include "sync_lane.h"
-
 // This file is compiled nine times (Makefile): part 0 holds every kernel with the reference's linear
 // interpolator, the one-wave kernels and the launch logic; parts 1-6 (-DDSP_SYNC_PART=n) only the
 // two-wave kernel with the Lagrange interpolator inside the timing loop (gardner2 / gardner_ted, half_len
@@ -34,6 +31,18 @@
 #ifndef DSP_SYNC_PART
 #define DSP_SYNC_PART 0
 #endif
+// dsp_math.h's bit select as one v_bfi_b32 (instead of the compiler's v_and + v_and_or / v_cndmask): measured per
+// part on one box (tools/ab_libs.sh, library built with -DDSP_NO_BFI against the product).  Part 0: fll_func alone
+// 0.68 -> 0.60 ms at 16 384 bursts, the fused two-wave kernel at 65 536 bursts 1.847 -> 1.840; part 7 (the timing
+// loop alone) 0.72 -> 0.69; part 8 (three live waves, <= 1 tile per CU) 0.749 -> 0.761 at 4096 bursts, 0.764 ->
+// 0.774 at 16 384: slower, so that part keeps the compiler's selects, as do the Lagrange parts (not measured).
+#if DSP_SYNC_PART != 0 && DSP_SYNC_PART != 7 && !defined(DSP_NO_BFI)
+#define DSP_NO_BFI
+#endif
+
+#include "dsp_internal.h"
+#include "sync_lane.h"
+
 
 #pragma clang fp contract(off)
 

@@ -15,7 +15,7 @@ for f in dsp_api sync_kernels tile_kernels fir_kernels synth_kernels segment_ker
   ( hipcc $FLAGS -c $SRC/$f.hip -o $OUT/$f.o && hipcc $FLAGS $SFLAGS $SRC/$f.hip -o $OUT/$f.lint.s ) & pids+=($!)
 done
 FLAGS_L="${FLAGS% $EXTRA} $EXTRA_LAGR"
-for part in 1 2 3 4 5 6; do
+for part in 1 2 3 4 5 6 7 8; do
 ( hipcc $FLAGS_L -DDSP_SYNC_PART=$part -c $SRC/sync_kernels.hip -o $OUT/sync_kernels_p$part.o &&
   hipcc $FLAGS_L -DDSP_SYNC_PART=$part $SFLAGS $SRC/sync_kernels.hip -o $OUT/sync_kernels_p$part.lint.s ) & pids+=($!)
 done
