@@ -326,23 +326,42 @@ DSP_HD double from_words(unsigned hi, unsigned lo)
     return x;
 }
 // mask ? a : b per bit (mask all ones or all zeros)
-DSP_HD unsigned bsel(unsigned mask, unsigned a, unsigned b)
-{
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(DSP_NO_BFI)      // (-DDSP_NO_BFI: A/B builds, tools/build_ab.sh)
-    // v_bfi_b32 D = (S0 & S1) | (~S0 & S2): ONE instruction; left to itself hipcc emits v_and_b32 + v_and_or_b32
-    // (with ~mask kept in a register) for this expression -- two issue slots per select on a wave that fills its
-    // SIMD's VALU by itself (119-132 instructions per symbol, tools/ubench/issue_latency.hip)
-    unsigned d;
-    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(mask), "v"(a), "v"(b));
-    return d;
+// v_bfi_b32 D = (S0 & S1) | (~S0 & S2): ONE instruction; left to itself hipcc emits v_and_b32 + v_and_or_b32 (with
+// ~mask kept in a register) or v_cndmask for this expression -- two issue slots per select on a wave that fills its
+// SIMD's VALU by itself (119-132 instructions per symbol).  Whether it pays is measured per kernel family
+// (profiles/r03_bfi_ab.txt) and chosen by the caller: SEL = 1 the asm form, 0 the plain expression.
+#if defined(DSP_NO_BFI)
+#define DSP_BFI_DEFAULT 0
 #else
-    return (a & mask) | (b & ~mask);
+#define DSP_BFI_DEFAULT 1
 #endif
-}
-DSP_HD double bsel64(unsigned mask, double a, double b)
+#if defined(DSP_NO_BFI_T)
+#define DSP_BFI_T_DEFAULT 0
+#else
+#define DSP_BFI_T_DEFAULT 1
+#endif
+template <int SEL>
+DSP_HD unsigned bsel_s(unsigned mask, unsigned a, unsigned b)
 {
-    return from_words(bsel(mask, hi_word(a), hi_word(b)), bsel(mask, lo_word(a), lo_word(b)));
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (SEL) {
+        unsigned d;
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(mask), "v"(a), "v"(b));
+        return d;
+    }
+#endif
+    return (a & mask) | (b & ~mask);
 }
+template <int SEL>
+DSP_HD double bsel64_s(unsigned mask, double a, double b)
+{
+    return from_words(bsel_s<SEL>(mask, hi_word(a), hi_word(b)), bsel_s<SEL>(mask, lo_word(a), lo_word(b)));
+}
+DSP_HD unsigned bsel(unsigned mask, unsigned a, unsigned b) { return bsel_s<DSP_BFI_DEFAULT>(mask, a, b); }
+DSP_HD double bsel64(unsigned mask, double a, double b) { return bsel64_s<DSP_BFI_DEFAULT>(mask, a, b); }
+// the timing loop's pick3 (sync_kernels.hip), switched on its own
+DSP_HD unsigned bsel_t(unsigned mask, unsigned a, unsigned b) { return bsel_s<DSP_BFI_T_DEFAULT>(mask, a, b); }
+DSP_HD double bsel64_t(unsigned mask, double a, double b) { return bsel64_s<DSP_BFI_T_DEFAULT>(mask, a, b); }
 
 // evidence of a block of fll_step_fast calls, kept as integers (high words): no compare, no select
 struct FllEvidence {
@@ -353,6 +372,7 @@ struct FllEvidence {
 DSP_HD void fll_evidence_init(FllEvidence &e) { e.zbad = 0u; e.kmax = 0u; }
 DSP_HD bool fll_evidence_bad(const FllEvidence &e) { return e.zbad >= 0x7fefffffu || e.kmax >= 0x41d00000u; }
 
+template <int SEL = DSP_BFI_DEFAULT>
 DSP_HD FllOut fll_step_fast(const MathK &K, double xr, double xi, double idx, double idx4, double &curr_freq,
                             double &integrator, double kp, double ki, FllEvidence &ev)
 {
@@ -373,8 +393,8 @@ DSP_HD FllOut fll_step_fast(const MathK &K, double xr, double xi, double idx, do
     const unsigned odd = 0u - ((unsigned)q & 1u);       // all ones when k is odd
     const unsigned neg_r = ((unsigned)q << 30) & 0x80000000u;
     const unsigned neg_i = (((unsigned)q + 1u) << 30) & 0x80000000u;
-    const double ar = from_words(bsel(odd, hi_word(xi), hi_word(xr)) ^ neg_r, bsel(odd, lo_word(xi), lo_word(xr)));
-    const double ai = from_words(bsel(odd, hi_word(xr), hi_word(xi)) ^ neg_i, bsel(odd, lo_word(xr), lo_word(xi)));
+    const double ar = from_words(bsel_s<SEL>(odd, hi_word(xi), hi_word(xr)) ^ neg_r, bsel_s<SEL>(odd, lo_word(xi), lo_word(xr)));
+    const double ai = from_words(bsel_s<SEL>(odd, hi_word(xr), hi_word(xi)) ^ neg_i, bsel_s<SEL>(odd, lo_word(xr), lo_word(xi)));
     double sn, cs;
     sincos_quarter(K, r, sn, cs);
     const double sr = ar * cs + ai * sn;                // :17
@@ -389,8 +409,8 @@ DSP_HD FllOut fll_step_fast(const MathK &K, double xr, double xi, double idx, do
     // second interval (t >= 7/16) <=> 7*S - 16*|D| < 0; at equality either interval serves
     const double c2d = fma3(-16.0, aD, 7.0 * S);
     const unsigned c2 = (unsigned)((int)hi_word(c2d) >> 31);
-    const double num = bsel64(c2, -mn, aD);
-    const double den = bsel64(c2, mx, S);
+    const double num = bsel64_s<SEL>(c2, -mn, aD);
+    const double den = bsel64_s<SEL>(c2, mx, S);
     const double hi = from_words(hi_word(K.v[K_PIO4_HI]) & c2, lo_word(K.v[K_PIO4_HI]) & c2);
     const double lo = from_words(hi_word(K.v[K_PIO4_LO]) & c2, lo_word(K.v[K_PIO4_LO]) & c2);
 #ifdef DSP_EXP_FLL_CHEAP          // experiment: which wave is the bottleneck (results are wrong)

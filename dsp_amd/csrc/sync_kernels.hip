@@ -39,6 +39,16 @@
 #if DSP_SYNC_PART != 0 && DSP_SYNC_PART != 7 && !defined(DSP_NO_BFI)
 #define DSP_NO_BFI
 #endif
+#if DSP_SYNC_PART != 0 && DSP_SYNC_PART != 7 && !defined(DSP_NO_BFI_T)
+#define DSP_NO_BFI_T
+#endif
+// ... except the FLL wave of part 8 on complex64 tiles, where it does pay (4096 bursts 0.746 -> 0.724 ms; complex128
+// tiles 0.760 -> 0.779 with it, and the timing wave's pick3 0.746 -> 0.757): fll_spec_block's FSEL
+#if DSP_SYNC_PART == 8 && !defined(DSP_P8_NO_BFI_F)
+#define DSP_P8_BFI_F 1
+#else
+#define DSP_P8_BFI_F 0
+#endif
 
 #include "dsp_internal.h"
 #include "sync_lane.h"
@@ -592,15 +602,15 @@ __device__ __forceinline__ cd widen(const IN v, const double scale)
 __device__ __forceinline__ f2v pick3(unsigned lt, unsigned gt, f2v a, f2v b, f2v c)
 {
     f2v r;
-    r.x = __uint_as_float(dspm::bsel(lt, __float_as_uint(a.x), dspm::bsel(gt, __float_as_uint(b.x), __float_as_uint(c.x))));
-    r.y = __uint_as_float(dspm::bsel(lt, __float_as_uint(a.y), dspm::bsel(gt, __float_as_uint(b.y), __float_as_uint(c.y))));
+    r.x = __uint_as_float(dspm::bsel_t(lt, __float_as_uint(a.x), dspm::bsel_t(gt, __float_as_uint(b.x), __float_as_uint(c.x))));
+    r.y = __uint_as_float(dspm::bsel_t(lt, __float_as_uint(a.y), dspm::bsel_t(gt, __float_as_uint(b.y), __float_as_uint(c.y))));
     return r;
 }
 __device__ __forceinline__ d2v pick3(unsigned lt, unsigned gt, d2v a, d2v b, d2v c)
 {
     d2v r;
-    r.x = dspm::bsel64(lt, a.x, dspm::bsel64(gt, b.x, c.x));
-    r.y = dspm::bsel64(lt, a.y, dspm::bsel64(gt, b.y, c.y));
+    r.x = dspm::bsel64_t(lt, a.x, dspm::bsel64_t(gt, b.x, c.x));
+    r.y = dspm::bsel64_t(lt, a.y, dspm::bsel64_t(gt, b.y, c.y));
     return r;
 }
 
@@ -860,7 +870,8 @@ __device__ __forceinline__ bool fll_spec_block(const dspm::MathK &MK, const int 
     for (int t = 0; t < n; t++) {
         qa += 1024u;
         const d2v xn = lds_ld<d2v>(qa);                  // next symbol's sample (behind the block: read, not used)
-        const dspm::FllOut o = dspm::fll_step_fast(MK, x.x, x.y, idx, idx4, f, g, kp, ki, ev);
+        constexpr int FSEL = (DSP_P8_BFI_F && sizeof(OC) == 8) ? 1 : DSP_BFI_DEFAULT;
+        const dspm::FllOut o = dspm::fll_step_fast<FSEL>(MK, x.x, x.y, idx, idx4, f, g, kp, ki, ev);
         const OC sv = {(OS)o.sr, (OS)o.si};
         if (MASK == 15) GS::c_s_s_b(off_c, sv, sb.sig_t, off_s, (OS)o.freq, sb.freq_t, (OS)o.ef, sb.ef_t, off_b, (unsigned)o.quad, sb.dec_t);
         else if (MASK == 11) GS::c_s_b(off_c, sv, sb.sig_t, off_s, (OS)o.freq, sb.freq_t, off_b, (unsigned)o.quad, sb.dec_t);
